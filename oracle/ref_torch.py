@@ -1,0 +1,374 @@
+"""fp32 CPU restatement of the rho-diffusion DDPM + UNetv2 hot path.
+
+TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  Functional style: weights come
+from a ``state_dict`` that uses the reference's key names, the
+network structure is re-derived from the constructor kwargs.  All citations are
+relative to ``/root/reference``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------- schedules
+def _sigma(alpha_bar64: Tensor, alpha_bar32: Tensor, beta64: Tensor) -> Tensor:
+    """sigma_t = sqrt((1 - abar_{t-1}) / (1 - abar_t) * beta_t), abar_{-1} = 1.
+
+    rho_diffusion/diffusion/schedule.py:79-82 (offset_alpha_bar_t is built from the
+    *stored fp32* alpha_bar, padded with 1.0 on the left) and :164-168 / :211-214.
+    """
+    offset = F.pad(alpha_bar32[:-1], (1, 0), value=1.0)
+    return torch.sqrt((1 - offset) / (1 - alpha_bar64) * beta64).to(torch.float32)
+
+
+def linear_schedule(num_steps: int, beta_1: float = 1.0e-3, beta_T: float = 0.02) -> Dict[str, Tensor]:
+    """rho_diffusion/diffusion/schedule.py:141-168 (LinearSchedule.__init__)."""
+    scale = 1000 / num_steps
+    beta = torch.linspace(scale * beta_1, scale * beta_T, num_steps, dtype=torch.float64)
+    alpha = 1.0 - beta
+    alpha_bar = alpha.cumprod(0)
+    abar32 = alpha_bar.to(torch.float32)
+    return {
+        "beta_t": beta.to(torch.float32),
+        "alpha_t": alpha.to(torch.float32),
+        "alpha_bar_t": abar32,
+        "sigma_t": _sigma(alpha_bar, abar32, beta),
+    }
+
+
+def cosine_schedule(num_steps: int, offset: float = 0.008) -> Dict[str, Tensor]:
+    """rho_diffusion/diffusion/schedule.py:171-214 (CosineBetaSchedule.__init__).
+
+    Quirks kept: T+1 entries; beta is computed from the *unclamped*
+    fp64 alpha_bar divided by the fp32 offset alpha_bar (so beta[0] = 1 - abar0/1 -> clip);
+    ``clip_`` is in-place so alpha_t = 1 - clipped beta; sigma[0] = sqrt(0/0*..) = NaN.
+    """
+    t = torch.linspace(0.0, num_steps, num_steps + 1, dtype=torch.float64) / num_steps
+    alpha_bar = torch.cos((t + offset) / (1 + offset) * math.pi * 0.5).pow(2.0)
+    alpha_bar = alpha_bar.div(alpha_bar[0])
+    abar32 = alpha_bar.to(torch.float32)
+    abar32[abar32 < 0] = 0
+    abar32[abar32 > 1] = 1
+    off32 = F.pad(abar32[:-1], (1, 0), value=1.0)
+    beta = 1 - (alpha_bar / off32)
+    beta = beta.clip_(0.0001, 0.9999)
+    return {
+        "alpha_bar_t": abar32,
+        "beta_t": beta.to(torch.float32),
+        "alpha_t": (1 - beta).to(torch.float32),
+        "sigma_t": torch.sqrt((1 - off32) / (1 - alpha_bar) * beta).to(torch.float32),
+    }
+
+
+# --------------------------------------------------------------------------- embeddings
+def sinusoidal_embedding(t: Tensor, dim: int, wavelength: int = 10000) -> Tensor:
+    """rho_diffusion/models/common.py:27-43: interleaved sin/cos, always fp32."""
+    assert dim % 2 == 0
+    i = torch.arange(dim // 2)
+    omega = torch.pow(wavelength, 2 * i / dim)
+    pe = torch.empty(len(t), dim)
+    pe[:, 2 * i] = torch.sin(t[:, None] / omega[None, :]).float()
+    pe[:, 2 * i + 1] = torch.cos(t[:, None] / omega[None, :]).float()
+    return pe
+
+
+def multi_embeddings(y: Tensor, parameter_space: Dict[str, Sequence[float]], sd: Dict[str, Tensor],
+                     prefix: str = "cond_fn.") -> Optional[Tensor]:
+    """rho_diffusion/models/conditioning.py:115-139 (MultiEmbeddings.forward):
+    per key (dict order) look up the position of y[:, i] in parameter_space[key] by exact
+    equality, embed, and sum over keys."""
+    emb = None
+    for i, key in enumerate(parameter_space.keys()):
+        yi = y if y.dim() == 1 else y[:, i]
+        space = torch.tensor(parameter_space[key])
+        categorical = torch.where(yi[:, None] == space[None, :])[1]
+        e = F.embedding(categorical, sd[f"{prefix}embedding_layers.{key}.weight"])
+        emb = e if emb is None else emb + e
+    return emb
+
+
+# --------------------------------------------------------------------------- layers
+def group_norm32(x: Tensor, w: Tensor, b: Tensor) -> Tensor:
+    """rho_diffusion/layers.py:71-74,122-129: GroupNorm(32, C), eps 1e-5, fp32 math."""
+    return F.group_norm(x.float(), 32, w, b, eps=1e-5).type(x.dtype)
+
+
+def conv_nd(dims: int, x: Tensor, w: Tensor, b: Optional[Tensor], stride=1, padding=0) -> Tensor:
+    """rho_diffusion/layers.py:77-88."""
+    return {1: F.conv1d, 2: F.conv2d, 3: F.conv3d}[dims](x, w, b, stride=stride, padding=padding)
+
+
+def upsample(dims: int, x: Tensor) -> Tensor:
+    """rho_diffusion/models/unet_v2.py:122-131: nearest x2; 3-D keeps depth."""
+    if dims == 3:
+        return F.interpolate(x, (x.shape[2], x.shape[3] * 2, x.shape[4] * 2), mode="nearest")
+    return F.interpolate(x, scale_factor=2, mode="nearest")
+
+
+def resblock(dims: int, x: Tensor, emb: Tensor, sd: Dict[str, Tensor], p: str,
+             use_scale_shift_norm: bool) -> Tensor:
+    """rho_diffusion/models/unet_v2.py:273-293 (ResBlock._forward, no up/down, dropout 0)."""
+    h = group_norm32(x, sd[p + "in_layers.0.weight"], sd[p + "in_layers.0.bias"])
+    h = conv_nd(dims, F.silu(h), sd[p + "in_layers.2.weight"], sd[p + "in_layers.2.bias"], padding=1)
+    emb_out = F.linear(F.silu(emb), sd[p + "emb_layers.1.weight"], sd[p + "emb_layers.1.bias"]).type(h.dtype)
+    while emb_out.dim() < h.dim():
+        emb_out = emb_out[..., None]
+    if use_scale_shift_norm:
+        scale, shift = torch.chunk(emb_out, 2, dim=1)
+        h = group_norm32(h, sd[p + "out_layers.0.weight"], sd[p + "out_layers.0.bias"]) * (1 + scale) + shift
+        h = conv_nd(dims, F.silu(h), sd[p + "out_layers.3.weight"], sd[p + "out_layers.3.bias"], padding=1)
+    else:
+        h = h + emb_out
+        h = group_norm32(h, sd[p + "out_layers.0.weight"], sd[p + "out_layers.0.bias"])
+        h = conv_nd(dims, F.silu(h), sd[p + "out_layers.3.weight"], sd[p + "out_layers.3.bias"], padding=1)
+    if (p + "skip_connection.weight") in sd:
+        w = sd[p + "skip_connection.weight"]
+        pad = 1 if w.shape[-1] == 3 else 0
+        x = conv_nd(dims, x, w, sd[p + "skip_connection.bias"], padding=pad)
+    return x + h
+
+
+def qkv_attention(qkv: Tensor, n_heads: int, new_order: bool) -> Tensor:
+    """rho_diffusion/models/unet_v2.py:374-393 (legacy) / 409-432 (new order)."""
+    bs, width, length = qkv.shape
+    assert width % (3 * n_heads) == 0
+    ch = width // (3 * n_heads)
+    scale = 1 / math.sqrt(math.sqrt(ch))
+    if new_order:
+        q, k, v = qkv.chunk(3, dim=1)
+        q = (q * scale).reshape(bs * n_heads, ch, length)
+        k = (k * scale).reshape(bs * n_heads, ch, length)
+        v = v.reshape(bs * n_heads, ch, length)
+    else:
+        q, k, v = qkv.reshape(bs * n_heads, ch * 3, length).split(ch, dim=1)
+        q, k = q * scale, k * scale
+    weight = torch.einsum("bct,bcs->bts", q, k)
+    weight = torch.softmax(weight.float(), dim=-1).type(weight.dtype)
+    a = torch.einsum("bts,bcs->bct", weight, v)
+    return a.reshape(bs, -1, length)
+
+
+def attention_block(x: Tensor, sd: Dict[str, Tensor], p: str, n_heads: int, new_order: bool) -> Tensor:
+    """rho_diffusion/models/unet_v2.py:336-342 (AttentionBlock._forward)."""
+    b, c, *spatial = x.shape
+    x = x.reshape(b, c, -1)
+    qkv = F.conv1d(group_norm32(x, sd[p + "norm.weight"], sd[p + "norm.bias"]), sd[p + "qkv.weight"], sd[p + "qkv.bias"])
+    h = qkv_attention(qkv, n_heads, new_order)
+    h = F.conv1d(h, sd[p + "proj_out.weight"], sd[p + "proj_out.bias"])
+    return (x + h).reshape(b, c, *spatial)
+
+
+# --------------------------------------------------------------------------- UNetv2
+def unet_structure(cfg: dict) -> dict:
+    """Replays the constructor loops of rho_diffusion/models/unet_v2.py:533-683 and returns,
+    per ``input_blocks`` / ``middle_block`` / ``output_blocks`` entry, the list of layer kinds
+    with their ``state_dict`` prefixes.  Supported: conv_resample=True, resblock_updown=False
+    (every shipped config)."""
+    mc = cfg["model_channels"]
+    mult = tuple(cfg.get("channel_mult", (1, 2, 4, 8)))
+    nres = cfg["num_res_blocks"]
+    attn_res = list(cfg.get("attention_resolutions", [16, 8]))
+    heads = cfg.get("num_heads", 1)
+    nhc = cfg.get("num_head_channels", -1)
+    heads_up = cfg.get("num_heads_upsample", -1)
+    if heads_up == -1:
+        heads_up = heads
+    assert cfg.get("conv_resample", True) and not cfg.get("resblock_updown", False)
+
+    def nh(c, h):
+        return h if nhc == -1 else c // nhc
+
+    inp: List[List[tuple]] = [[("conv", "input_blocks.0.0.")]]
+    ch = int(mult[0] * mc)
+    chans = [ch]
+    ds = 1
+    for level, m in enumerate(mult):
+        for _ in range(nres):
+            idx = len(inp)
+            layers = [("res", f"input_blocks.{idx}.0.", ch, int(m * mc))]
+            ch = int(m * mc)
+            if ds in attn_res:
+                layers.append(("attn", f"input_blocks.{idx}.1.", ch, nh(ch, heads)))
+            inp.append(layers)
+            chans.append(ch)
+        if level != len(mult) - 1:
+            idx = len(inp)
+            inp.append([("down", f"input_blocks.{idx}.0.op.", ch)])
+            chans.append(ch)
+            ds *= 2
+    mid = [("res", "middle_block.0.", ch, ch), ("attn", "middle_block.1.", ch, nh(ch, heads)),
+           ("res", "middle_block.2.", ch, ch)]
+    out: List[List[tuple]] = []
+    for level, m in list(enumerate(mult))[::-1]:
+        for i in range(nres + 1):
+            ich = chans.pop()
+            idx = len(out)
+            layers = [("res", f"output_blocks.{idx}.0.", ch + ich, int(mc * m))]
+            ch = int(mc * m)
+            if ds in attn_res:
+                layers.append(("attn", f"output_blocks.{idx}.{len(layers)}.", ch, nh(ch, heads_up)))
+            if level and i == nres:
+                layers.append(("up", f"output_blocks.{idx}.{len(layers)}.conv.", ch))
+                ds //= 2
+            out.append(layers)
+    return {"input": inp, "middle": mid, "output": out, "final_ch": ch}
+
+
+def _run_layers(dims, layers, h, emb, sd, cfg):
+    ssn = bool(cfg.get("use_scale_shift_norm", False))
+    new_order = bool(cfg.get("use_new_attention_order", False))
+    for layer in layers:
+        kind, p = layer[0], layer[1]
+        if kind == "conv":
+            h = conv_nd(dims, h, sd[p + "weight"], sd[p + "bias"], padding=1)
+        elif kind == "res":
+            h = resblock(dims, h, emb, sd, p, ssn)
+        elif kind == "attn":
+            h = attention_block(h, sd, p, layer[3], new_order)
+        elif kind == "down":
+            stride = 2 if dims != 3 else (1, 2, 2)  # unet_v2.py:153
+            h = conv_nd(dims, h, sd[p + "weight"], sd[p + "bias"], stride=stride, padding=1)
+        elif kind == "up":
+            h = conv_nd(dims, upsample(dims, h), sd[p + "weight"], sd[p + "bias"], padding=1)
+    return h
+
+
+def unet_embedding(sd, cfg, timesteps: Tensor, y: Optional[Tensor] = None,
+                   parameter_space=None) -> Tensor:
+    """rho_diffusion/models/unet_v2.py:694-719."""
+    mc = cfg["model_channels"]
+    num_classes = cfg.get("num_classes", None)
+    assert (y is not None) == (num_classes is not None)
+    e = sinusoidal_embedding(timesteps, mc)
+    e = F.linear(e, sd["time_embed.0.weight"], sd["time_embed.0.bias"])
+    e = F.linear(F.silu(e), sd["time_embed.2.weight"], sd["time_embed.2.bias"])
+    if num_classes is not None:
+        if y.dim() == 2 and y.shape == e.shape:
+            e = e + y
+        else:
+            e = e + multi_embeddings(y, parameter_space, sd)
+    return e
+
+
+def unet_forward(sd: Dict[str, Tensor], cfg: dict, x: Tensor, timesteps: Tensor,
+                 y: Optional[Tensor] = None, parameter_space=None) -> Tensor:
+    """rho_diffusion/models/unet_v2.py:685-732 (UNet.forward)."""
+    dims = cfg.get("dims", 2)
+    st = unet_structure(cfg)
+    emb = unet_embedding(sd, cfg, timesteps, y, parameter_space)
+    hs = []
+    h = x.float()
+    for layers in st["input"]:
+        h = _run_layers(dims, layers, h, emb, sd, cfg)
+        hs.append(h)
+    h = _run_layers(dims, st["middle"], h, emb, sd, cfg)
+    for layers in st["output"]:
+        h = torch.cat([h, hs.pop()], dim=1)
+        h = _run_layers(dims, layers, h, emb, sd, cfg)
+    h = group_norm32(h, sd["out.0.weight"], sd["out.0.bias"])
+    return conv_nd(dims, F.silu(h), sd["out.2.weight"], sd["out.2.bias"], padding=1)
+
+
+# --------------------------------------------------------------------------- DDPM
+def _bshape(x: Tensor, v: Tensor) -> Tensor:
+    """rho_diffusion/diffusion/abstract_diffusion.py:171-192 (reshape_timesteps)."""
+    return v.view((-1, *((1,) * (x.dim() - 1))))
+
+
+def q_sample(x0: Tensor, t: Tensor, noise: Tensor, alpha_bar: Tensor) -> Tensor:
+    """rho_diffusion/diffusion/ddpm.py:104-130 (forward_process) with the noise injected:
+    x_t = sqrt(abar[t]) * x0 + sqrt(1 - abar[t]) * eps (abar cast to the data dtype first)."""
+    ab = _bshape(x0, alpha_bar.type(x0.dtype)[t])
+    return ab.sqrt() * x0 + (1 - ab).sqrt() * noise
+
+
+def p_sample_step(x_t: Tensor, pred_noise: Tensor, t: int, sched: Dict[str, Tensor], z: Tensor) -> Tensor:
+    """rho_diffusion/diffusion/ddpm.py:210-218: one reverse update (callers skip it at t == 0).
+    Noise scale is 0.8*sqrt(beta_t) (q2), result clamped to [-1, 1] (q4)."""
+    a, b, ab = (sched[k].type(x_t.dtype)[t] for k in ("alpha_t", "beta_t", "alpha_bar_t"))
+    x = (1 / a.sqrt()) * (x_t - (b / (1 - ab).sqrt()) * pred_noise) + 0.8 * torch.sqrt(b) * z
+    return torch.clamp(x, -1, 1)
+
+
+def reverse_process(model, x_init: Tensor, sched: Dict[str, Tensor], z_tape: Sequence[Tensor],
+                    conditions=None, num_checkpoints: int = 0):
+    """rho_diffusion/diffusion/ddpm.py:132-229 with the RNG replaced by a tape: ``x_init`` is
+    the first ``randn_like`` draw (:171) and ``z_tape[i]`` the i-th later draw, taken only when
+    t > 1 and *before* the backbone call (:196-199).  ``model(x, tt, cond)`` predicts eps.
+    Returns (denoised, buffer-or-None) with the q5 checkpoint rule (T // 10 spacing)."""
+    T = len(sched["alpha_bar_t"])
+    steps_per_ckpt = T // 10
+    x_t = x_init.clone()
+    B = x_t.shape[0]
+    buf = torch.zeros((B, num_checkpoints) + tuple(x_t.shape[1:])) if num_checkpoints else None
+    zi = 0
+    t_idx = 0
+    for t in range(T - 1, -1, -1):
+        if t > 1:
+            z = z_tape[zi]
+            zi += 1
+        else:
+            z = torch.zeros_like(x_t)
+        tt = torch.full((B,), t, dtype=torch.long)
+        pred = model(x_t, tt, conditions)
+        if t > 0:
+            x_t = p_sample_step(x_t, pred, t, sched, z)
+        if buf is not None and t % steps_per_ckpt == 0 and t_idx < num_checkpoints:
+            buf[:, t_idx] = x_t
+            t_idx += 1
+    return x_t, buf
+
+
+def training_loss(model, x0: Tensor, t: Tensor, noise: Tensor, alpha_bar: Tensor, labels=None) -> Tensor:
+    """rho_diffusion/diffusion/ddpm.py:231-288 with (t, eps) injected: MSE(eps_hat, eps)."""
+    x_t = q_sample(x0, t, noise, alpha_bar)
+    pred = model(x_t, t, labels)
+    return F.mse_loss(pred, noise)
+
+
+def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, beta1=0.9, beta2=0.999,
+               eps=1e-8, weight_decay=1e-2):
+    """torch.optim.AdamW single-tensor update (abstract_diffusion.py:103-119 builds it with
+    PyTorch defaults): decoupled decay, bias-corrected moments.  Returns (p, m, v)."""
+    p = p * (1 - lr * weight_decay)
+    m = beta1 * m + (1 - beta1) * g
+    v = beta2 * v + (1 - beta2) * g * g
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)) + eps
+    p = p - (lr / bc1) * (m / denom)
+    return p, m, v
+
+
+# --------------------------------------------------------------------------- inputs
+def spherical_harmonic_field(l: int, m: int, grid: int, dims: int = 3):
+    """Density field of rho_diffusion/data/synthetic.py:45-124 on linspace(-2, 2, G)^3:
+    |Y_l^{|m|}(theta, phi) * r| min-max normalised; 2-D = central z slice (the reference
+    has no 2-D generator; choice stated in SURVEY 8d).  Returns float32 [1, G, G(, G)]."""
+    import numpy as np
+    try:
+        from scipy.special import sph_harm_y
+
+        def sph(mm, ll, th, ph):  # scipy>=1.15: sph_harm_y(n, m, polar, azimuth)
+            return sph_harm_y(ll, mm, ph, th)
+    except ImportError:  # pragma: no cover
+        from scipy.special import sph_harm as sph
+    ax = np.linspace(-2, 2, grid)
+    xg, yg, zg = np.meshgrid(ax, ax, ax, indexing="xy")
+    with np.errstate(divide="ignore", invalid="ignore"):
+        theta = np.arctan(np.sqrt(xg ** 2 + yg ** 2) / zg)
+        phi = np.arctan(yg / xg)
+    radial = np.sqrt(xg ** 2 + yg ** 2 + zg ** 2)
+    # reference: sph_harm(|m|, l, theta, phi) with scipy's legacy (m, n, azimuth, polar) order
+    sol = sph(abs(m), l, theta, phi) * radial
+    sol = (sol - sol.min()) / (sol.max() - sol.min())
+    out = np.abs(sol).astype(np.float32)
+    if dims == 2:
+        out = out[:, :, grid // 2]
+    return torch.from_numpy(out)[None]

@@ -1,0 +1,151 @@
+"""Pin the CPU oracle (oracle/ref_torch.py) against vectors produced by the real reference
+(tests/golden/make_golden.py) and the reference's own known-answer test."""
+import numpy as np
+import pytest
+import torch
+from pytest import approx
+
+from helpers import (PARAM_SPACE, UNET_CASES, case_inputs, det_normal, det_state_dict, det_uniform,
+                     golden_template, grad_digest_of, load_golden, rel_l2)
+from oracle import ref_torch as R
+
+torch.set_num_threads(4)
+TOL = 2e-5  # fp32 rel-L2; oracle-vs-reference only differs by op ordering
+
+
+def test_reference_known_answers_schedule():
+    """reference tests/pipeline/test_schedule.py:28-46."""
+    s = R.linear_schedule(100, 1e-4, 0.02)
+    assert len(s["beta_t"]) == 100
+    assert s["beta_t"][0] == 0.001 and s["beta_t"][-1] == 0.2
+    assert s["alpha_t"][0] == 0.999 and s["alpha_t"][-1] == 0.8
+    assert s["sigma_t"][0] == 0.0
+    assert approx(float(s["sigma_t"][-1]), 1e-4) == 0.4472
+
+
+def test_g1_schedules():
+    g = load_golden("g1_schedules.npz")
+    for key in g.files:
+        name, arr = key.split("/")
+        parts = name.split("_")
+        if parts[0] == "lin":
+            s = R.linear_schedule(int(parts[1]), float(parts[2]), float(parts[3]))
+        else:
+            s = R.cosine_schedule(int(parts[1]))
+        np.testing.assert_array_equal(s[arr].numpy(), g[key], err_msg=key)  # bit-exact incl. NaN position
+
+
+def test_g2_sinusoid():
+    g = load_golden("g2_sinusoid.npz")
+    t = torch.from_numpy(g["t"])
+    for dim in (32, 64, 128):
+        np.testing.assert_array_equal(R.sinusoidal_embedding(t, dim).numpy(), g[f"dim{dim}"])
+
+
+def _sd(template_mod_keys, salt):
+    return det_state_dict(template_mod_keys, salt)
+
+
+def test_g3_modules():
+    g = load_golden("g3_modules.npz")
+    E = 128
+    for name, dims, cin, cout, shape in [("res2d_same", 2, 32, 32, (2, 32, 8, 12)), ("res2d_wide", 2, 32, 64, (2, 32, 8, 12)),
+                                         ("res3d_wide", 3, 64, 32, (2, 64, 4, 6, 8)), ("res3d_same", 3, 32, 32, (1, 32, 5, 4, 8))]:
+        k = (3,) * dims
+        for ssn in (True, False):
+            tmpl = {"in_layers.0.weight": torch.empty(cin), "in_layers.0.bias": torch.empty(cin),
+                    "in_layers.2.weight": torch.empty(cout, cin, *k), "in_layers.2.bias": torch.empty(cout),
+                    "emb_layers.1.weight": torch.empty(2 * cout if ssn else cout, E),
+                    "emb_layers.1.bias": torch.empty(2 * cout if ssn else cout),
+                    "out_layers.0.weight": torch.empty(cout), "out_layers.0.bias": torch.empty(cout),
+                    "out_layers.3.weight": torch.empty(cout, cout, *k), "out_layers.3.bias": torch.empty(cout)}
+            if cin != cout:
+                tmpl["skip_connection.weight"] = torch.empty(cout, cin, *((1,) * dims))
+                tmpl["skip_connection.bias"] = torch.empty(cout)
+            sd = det_state_dict(tmpl, name)
+            y = R.resblock(dims, det_normal(shape, name + "x"), det_normal((shape[0], E), name + "emb"), sd, "", ssn)
+            assert rel_l2(y, torch.from_numpy(g[f"{name}_ssn{int(ssn)}/y"])) < TOL, (name, ssn)
+    for name, c, heads, shape in [("attn2d", 64, 4, (2, 64, 8, 8)), ("attn3d", 64, 2, (2, 64, 4, 8, 8)), ("attn2d_h1", 32, 1, (1, 32, 4, 4))]:
+        tmpl = {"norm.weight": torch.empty(c), "norm.bias": torch.empty(c), "qkv.weight": torch.empty(3 * c, c, 1),
+                "qkv.bias": torch.empty(3 * c), "proj_out.weight": torch.empty(c, c, 1), "proj_out.bias": torch.empty(c)}
+        sd = det_state_dict(tmpl, name)
+        for new in (False, True):
+            y = R.attention_block(det_normal(shape, name + "x"), sd, "", heads, new)
+            assert rel_l2(y, torch.from_numpy(g[f"{name}_new{int(new)}/y"])) < TOL, (name, new)
+    for name, dims, c, shape in [("down3d", 3, 32, (2, 32, 4, 8, 8)), ("down2d", 2, 32, (2, 32, 8, 8)), ("down1d", 1, 32, (2, 32, 16))]:
+        k = (3,) * dims
+        x = det_normal(shape, name + "x")
+        sd = det_state_dict({"op.weight": torch.empty(c, c, *k), "op.bias": torch.empty(c)}, name)
+        y = R._run_layers(dims, [("down", "op.", c)], x, None, sd, {})
+        assert rel_l2(y, torch.from_numpy(g[f"{name}/y"])) < TOL, name
+        sd = det_state_dict({"conv.weight": torch.empty(c, c, *k), "conv.bias": torch.empty(c)}, name + "up")
+        y = R._run_layers(dims, [("up", "conv.", c)], x, None, sd, {})
+        assert rel_l2(y, torch.from_numpy(g[f"{name}_up/y"])) < TOL, name
+    sd = det_state_dict({"weight": torch.empty(64), "bias": torch.empty(64)}, "gn")
+    y = R.group_norm32(det_normal((2, 64, 3, 5, 7), "gnx") * 3 + 1.5, sd["weight"], sd["bias"])
+    assert rel_l2(y, torch.from_numpy(g["gn/y"])) < TOL
+
+
+@pytest.mark.parametrize("case", list(UNET_CASES.keys()))
+def test_g4_unet_forward_and_grads(case):
+    g = load_golden("g4_unet.npz")
+    cfg, x, t, y = case_inputs(case)
+    sd = det_state_dict(golden_template(g, case), case)
+    sd = {k: v.requires_grad_(True) for k, v in sd.items()}
+    pred = R.unet_forward(sd, cfg, x, t, y, PARAM_SPACE)
+    gold = torch.from_numpy(g[f"{case}/pred"])
+    assert pred.shape == gold.shape
+    assert rel_l2(pred, gold) < TOL
+    loss = torch.nn.functional.mse_loss(pred, det_normal(tuple(pred.shape), case + "tgt"))
+    assert abs(loss.item() - float(g[f"{case}/loss"])) < 1e-5
+    loss.backward()
+    checked = 0
+    for k, v in sd.items():
+        key = f"{case}/grad/{k}"
+        if key in g.files and v.grad is not None:
+            d, ref = grad_digest_of(v.grad), g[key]
+            assert abs(d[0] - ref[0]) <= 1e-4 * ref[0] + 1e-6, k
+            checked += 1
+    assert checked > 20
+
+
+@pytest.mark.parametrize("T", [50, 100])
+def test_g5_ddpm(T):
+    g = load_golden("g5_ddpm.npz")
+    g4 = load_golden("g4_unet.npz")
+    case = "tiny2d"
+    cfg, _, _, _ = case_inputs(case)
+    xshape = UNET_CASES[case][1]
+    sd = det_state_dict(golden_template(g4, case), case)
+    sched = R.linear_schedule(T, 1e-3, 0.02)
+    x0 = det_uniform(xshape, "x0", 0.0, 1.0)
+    eps = det_normal(xshape, "eps")
+    tq = torch.from_numpy(g[f"T{T}/t"])
+    xt = R.q_sample(x0, tq, eps, sched["alpha_bar_t"])
+    assert rel_l2(xt, torch.from_numpy(g[f"T{T}/q_sample"])) < 1e-6
+
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    model = lambda x, t, c: R.unet_forward(sdg, cfg, x, t)  # noqa: E731
+    loss = R.training_loss(model, x0, tq, eps, sched["alpha_bar_t"])
+    assert abs(loss.item() - float(g[f"T{T}/train_loss"])) < 1e-5
+    loss.backward()
+    for k, v in sdg.items():
+        ref = g[f"T{T}/train_grad/{k}"]
+        assert abs(grad_digest_of(v.grad)[0] - ref[0]) <= 1e-4 * ref[0] + 1e-6, k
+
+    tape = [det_normal(xshape, f"tape{T}_{i}") for i in range(T)]
+    with torch.no_grad():
+        model = lambda x, t, c: R.unet_forward(sd, cfg, x, t)  # noqa: E731
+        den, buf = R.reverse_process(model, tape[0], sched, tape[1:], None, num_checkpoints=3)
+    assert rel_l2(den, torch.from_numpy(g[f"T{T}/denoised"])) < 1e-3  # chaotic chain: looser
+    assert rel_l2(buf, torch.from_numpy(g[f"T{T}/buffer"])) < 1e-3
+
+
+def test_g8_adamw():
+    g = load_golden("g8_adamw.npz")
+    p = det_normal((257,), "adam_p")
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    for step in range(1, 4):
+        p, m, v = R.adamw_step(p, det_normal((257,), f"adam_g{step}"), m, v, step, lr=1e-4)
+        assert rel_l2(p, torch.from_numpy(g[f"p{step}"])) < 1e-6
