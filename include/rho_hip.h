@@ -1,0 +1,174 @@
+/*
+ * rho_hip.h -- C ABI of librho_hip.so: the MI355X (gfx950) kernels behind the
+ * rho_diffusion DDPM / UNetv2 hot path.
+ *
+ * The reference (intel/rho-diffusion) has no FFI of its own: its hot path is stock
+ * PyTorch ops called from Python.  Each entry point below therefore cites the reference
+ * *operator* (file:line under /root/reference) whose arithmetic it replaces; the Python
+ * classes in rho_diffusion_amd/ that mirror the reference's class surface call these
+ * through ctypes.
+ *
+ * Conventions
+ *  - Every function is asynchronous on the caller's hipStream_t (passed as void*),
+ *    allocates nothing, never synchronises, and returns 0 on success, a negative
+ *    RHO_E_* code for bad arguments, or a positive hipError_t from the launch.
+ *  - Pointers are device pointers unless stated otherwise.
+ *  - dtype: RHO_F32 = 0 (float), RHO_BF16 = 1 (bfloat16 storage, fp32 accumulate).
+ *  - "channels-last" activations are [N, D, H, W, C] contiguous (2-D: D = 1, 1-D: D = H = 1).
+ *    Tensors at the pipeline boundary (x_t, eps, eps_hat) keep the reference's
+ *    [N, C, *spatial] float32 layout.
+ */
+#ifndef RHO_HIP_H
+#define RHO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RHO_F32 0
+#define RHO_BF16 1
+
+#define RHO_E_ARG (-1)      /* inconsistent or unsupported argument */
+#define RHO_E_ALIGN (-2)    /* pointer / channel count not aligned as required */
+#define RHO_E_SHAPE (-3)    /* tile / shape constraint violated */
+
+/* library identification: returns the ABI version (bumped on any signature change) */
+int rho_abi_version(void);
+/* static string: target arch + build flags */
+const char* rho_build_info(void);
+
+/* ------------------------------------------------------------------ diffusion loops */
+
+/* q_sample: x_t = sqrt(abar[t_b]) * x0 + sqrt(1 - abar[t_b]) * eps     (per batch element b)
+ * replaces DDPM.forward_process, rho_diffusion/diffusion/ddpm.py:104-130 (+ the gather of
+ * abstract_diffusion.py:171-220).  x0/eps/x_t: float32 [B, per_sample]; abar: float32 [T];
+ * t: int64 [B].  nan_flag (optional, int32[1]) is set to 1 if any x_t is NaN: the device-side
+ * form of the host check at ddpm.py:268-272. */
+int rho_q_sample(const float* x0, const float* eps, float* x_t, const float* alpha_bar,
+                 const int64_t* t, int64_t batch, int64_t per_sample, int32_t* nan_flag, void* stream);
+
+/* p_sample_step: x <- clamp((x - beta/sqrt(1-abar) * eps_hat)/sqrt(alpha) + 0.8*sqrt(beta)*z, -1, 1)
+ * replaces ddpm.py:210-218 (one reverse update, caller skips t == 0; z may be NULL => 0,
+ * the t <= 1 case of ddpm.py:196-199).  coef = {1/sqrt(alpha_t), beta_t/sqrt(1-abar_t), 0.8*sqrt(beta_t)}
+ * as float32[3] on the DEVICE (row t of a [T,3] table built once per schedule) so a captured
+ * HIP graph can be replayed with a different row pointer-free: the row index is read from
+ * *t_dev (int32[1], device).  x updated in place; n elements. */
+int rho_p_sample_step(float* x, const float* eps_hat, const float* z, const float* coef_table,
+                      const int32_t* t_dev, int64_t n, void* stream);
+
+/* Device-resident loop state of reverse_process (ddpm.py:195): *t_dev -= 1 and *offset_dev += delta,
+ * so that one captured HIP graph replays every step without host involvement. Either may be NULL. */
+int rho_step_advance(int32_t* t_dev, uint64_t* offset_dev, uint64_t delta, void* stream);
+
+/* Counter-based Philox4x32-10 standard normals (Box-Muller), replaces torch.randn_like at
+ * ddpm.py:101-102,171,197.  out float32[n]; stream of (seed, offset) is reproducible and
+ * independent of launch geometry.  offset is read from *offset_dev (uint64[1], device) when
+ * offset_dev != NULL (graph-replayable), else from `offset`. */
+int rho_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset,
+                      const uint64_t* offset_dev, void* stream);
+
+/* mean((a-b)^2) -> loss[0] (float32, zeroed by this call) and optionally grad_a = 2(a-b)/n.
+ * replaces nn.MSELoss at ddpm.py:280 (+ its backward). */
+int rho_mse(const float* a, const float* b, float* loss, float* grad_a, int64_t n, void* stream);
+
+/* Fused multi-tensor-free AdamW over one flat float32 parameter arena
+ * (torch.optim.AdamW built at abstract_diffusion.py:103-119): decoupled weight decay,
+ * bias correction from `step` (1-based).  p, g, m, v: float32[n]. */
+int rho_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+              float beta2, float eps, float weight_decay, int32_t step, void* stream);
+
+/* ------------------------------------------------------------------ embeddings */
+
+/* out[b, :] = table[t[b], :]   (float32 [rows, dim] table; rows of the interleaved sin/cos
+ * timestep embedding of rho_diffusion/models/common.py:27-43).  t is int64[B]; when
+ * t_scalar_dev != NULL every b uses *t_scalar_dev (int32[1], device) instead. */
+int rho_embed_gather(const float* table, const int64_t* t, const int32_t* t_scalar_dev,
+                     float* out, int64_t batch, int64_t dim, int64_t rows, void* stream);
+
+/* out[b, o] = bias[o] + sum_k act(x[b, k]) * w[o, k] (+ add[b, o])   all float32.
+ * act_in: 0 = identity, 1 = SiLU.  act_out: 0 = identity, 1 = SiLU.
+ * replaces the nn.Linear / SiLU chains of unet_v2.py:521-525 (time_embed), :229-235
+ * (emb_layers of every ResBlock, batched by concatenating their weights) and the label
+ * embedding add of :702-719. */
+int rho_linear(const float* x, const float* w, const float* bias, const float* add, float* out,
+               int64_t batch, int64_t in_dim, int64_t out_dim, int act_in, int act_out, void* stream);
+
+/* ------------------------------------------------------------------ layout */
+
+/* [N, C, S] float32 (reference layout) -> channels-last [N, S, Cpad] dtype, channels >= C zeroed. */
+int rho_pack_input(const float* x, void* y, int dtype, int64_t n, int64_t c, int64_t s, int64_t cpad, void* stream);
+
+/* Conv weight [Cout, Cin, kd, kh, kw] float32 (PyTorch layout) -> [taps][CoutP][CinP] dtype,
+ * zero padded.  Optional row permutation `row_src` (int32[CoutP], device; -1 = zero row) lets
+ * the qkv projection be re-ordered (legacy vs new attention order, unet_v2.py:384,419-431). */
+int rho_prep_conv_weight(const float* w, void* out, int dtype, int64_t cout, int64_t cin, int64_t taps,
+                         int64_t coutp, int64_t cinp, const int32_t* row_src, void* stream);
+
+/* ------------------------------------------------------------------ GroupNorm (32 groups) */
+
+/* Pass 1: per-(sample, block, channel-octet) partial sums over channels-last input that may be
+ * the virtual concat of two tensors (torch.cat at unet_v2.py:729 is never materialised).
+ * partials: float32 [N][nblk][C/8][16] (8 sums, 8 sums of squares).  Returns required nblk via
+ * rho_gn_nblk.  replaces the statistics half of GroupNorm32.forward, layers.py:71-74. */
+int rho_gn_nblk(int64_t s);
+int rho_gn_partial(const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype,
+                   int64_t n, int64_t s, float* partials, void* stream);
+
+/* Pass 2: mean / rstd per (n, group) (eps 1e-5, biased variance) and the folded per-(n, channel)
+ * affine used by the conv prologue:   y = a*x + b  with
+ *   a = rstd*gamma*(1+scale),  b = (beta - mean*rstd*gamma)*(1+scale) + shift
+ * where scale/shift ([N, C] each, row stride film_stride floats) are the FiLM halves of
+ * unet_v2.py:285-289 (NULL => no FiLM: plain GroupNorm affine).  stats: float32 [N][32][2]. */
+int rho_gn_finalize(const float* partials, int64_t n, int64_t c, int64_t s, int64_t nblk,
+                    const float* gamma, const float* beta, const float* scale, const float* shift,
+                    int64_t film_stride, float* stats, float* a, float* b, void* stream);
+
+/* ------------------------------------------------------------------ convolution */
+
+typedef struct rho_conv_desc {
+    const void* x1;        /* channels-last input, c1 channels */
+    const void* x2;        /* optional second input (virtual concat after x1), c2 channels */
+    const float* pre_a;    /* optional prologue y = act(a*x+b), [N, c1+c2]; NULL = raw input */
+    const float* pre_b;
+    const void* w;         /* prepared weights [taps][coutp][c1+c2] */
+    const float* bias;     /* [coutp] float32 */
+    const void* res;       /* optional residual, channels-last [.., split], added in the epilogue */
+    const float* res_add;  /* optional per-(n, co) float32 added in the epilogue (additive timestep embedding,
+                              unet_v2.py:291): element (n, co) at res_add[n * res_add_stride + co] */
+    void* y;               /* channels-last output for co < split: [N, Do, Ho, Wo, split] */
+    void* y2;              /* channel-major output for split <= co < cout: [N, cout-split, Do*Ho*Wo] */
+    int32_t dtype;         /* of x1, x2, w, res, y */
+    int32_t y2_f32;        /* 1: y2 is float32 regardless of dtype */
+    int32_t c1, c2;
+    int32_t cout, coutp, split;
+    int32_t n, d, h, w_;   /* input extents (pre-upsample) */
+    int32_t kd, kh, kw;    /* 1 or 3 each; allowed: (3,3,3) (1,3,3) (1,1,3) (1,1,1) */
+    int32_t sh, sw;        /* stride on H / W (1 or 2); depth stride is always 1 (unet_v2.py:153) */
+    int32_t up_h, up_w;    /* nearest x2 upsample folded into the loader (unet_v2.py:122-131) */
+    int32_t pre_silu;      /* apply SiLU after the affine prologue */
+    int32_t res_add_stride;
+} rho_conv_desc;
+
+/* n-D convolution, zero padding k/2, as an LDS-halo-staged implicit GEMM on MFMA.
+ * replaces conv_nd (layers.py:77-88) at every call site of unet_v2.py (ResBlock convs :215,
+ * :241; skip 1x1 :256; Downsample :153-162; Upsample+conv :122-134; attention qkv / proj_out
+ * :323,:331 with the residual of :342; stem :535; head :679-683) with the GroupNorm affine +
+ * FiLM + SiLU (:212-216, :285-289) applied while the halo tile is staged. */
+int rho_conv_nd_fwd(const rho_conv_desc* desc, void* stream);
+
+/* ------------------------------------------------------------------ attention */
+
+/* Flash-style self attention, fp32 online softmax (QKVAttentionLegacy / QKVAttention,
+ * unet_v2.py:365-436, with the head order resolved at weight-prep time).
+ * qk: channels-last [B, T, 2C] (q of head h at h*ch, k at C + h*ch); vt: channel-major
+ * [B, C, T]; out: channels-last [B, T, C].  logits = (q.k) * ch^-0.5 (== scaling q and k by
+ * ch^-0.25 each, :385,:420).  ch in {16, 32, 64, 128, 256}. */
+int rho_attention_fwd(const void* qk, const void* vt, void* out, int dtype, int64_t batch, int64_t t,
+                      int64_t heads, int64_t ch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RHO_HIP_H */

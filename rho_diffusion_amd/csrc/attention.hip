@@ -1,0 +1,285 @@
+// Self-attention of the UNet's AttentionBlock (rho_diffusion/models/unet_v2.py:365-436) as a
+// flash-style kernel: the [T, T] logits (4.3 GB per head at T = 32768 in the reference) never
+// exist; fp32 online softmax, MFMA only for the QK^T and PV contractions.
+//
+// Data: qk channels-last [B, T, 2C] (q of head h at h*ch, k at C + h*ch), vt channel-major
+// [B, C, T] -- both written by the qkv 1x1 projection's epilogue -- and out channels-last [B, T, C].
+//
+// One workgroup = 4 waves = 128 queries of one (batch, head); a wave owns 32 queries.
+//   S^T[key][query] = K * Q^T   (v_mfma_f32_32x32x16_bf16: A = K rows from LDS, B = Q in registers)
+// puts the query on the lane and the 32 keys of a tile in the 16 accumulator registers of the two
+// half-waves, so the row max / row sum are in-register reductions plus ONE lane^32 exchange.
+// K rows are fetched in the permuted order pi (bits 2 and 3 of the row swapped): the accumulator
+// of S^T, converted pairwise to bf16, then IS the B operand of
+//   O^T[c][query] += V^T[c][key] * P^T[key][query]
+// with V^T read as plain 16-byte rows of 8 consecutive keys (A operand) -- no transposes, no LDS
+// round trip for P (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's operand").
+#include "common.h"
+
+template <int CH, int KT>  // KT keys per LDS tile (64; 32 for CH = 256 to stay inside static LDS)
+__global__ __launch_bounds__(256) void k_attn_bf16(const bf16_raw* __restrict__ qk, const bf16_raw* __restrict__ vt,
+                                                   bf16_raw* __restrict__ out, int T, int C, float scale_log2e) {
+    constexpr int KP = CH * 2 + 16;   // K tile row pitch (bytes): odd number of 16-B slots => conflict-free
+    constexpr int VP = KT * 2 + 16;   // V^T tile row pitch
+    constexpr int NKK = CH / 16;      // k-steps of the QK^T contraction
+    constexpr int NCT = (CH + 31) / 32;  // 32-row channel tiles of O^T
+    constexpr int NU = KT / 32;          // 32-key sub-tiles per LDS tile
+    __shared__ __attribute__((aligned(16))) char k_lds[KT * KP];
+    __shared__ __attribute__((aligned(16))) char v_lds[NCT * 32 * VP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int qi = q0 + col;
+    const size_t row2c = (size_t)2 * C;
+
+    // ---- Q fragments (B operand): 8 consecutive channels of this lane's query per k-step
+    uint4 qf[NKK];
+    {
+        const int qc = qi < T ? qi : T - 1;
+        const bf16_raw* qp = qk + ((size_t)b * T + qc) * row2c + (size_t)h * CH + 8 * half;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) qf[kk] = *reinterpret_cast<const uint4*>(qp + 16 * kk);
+    }
+
+    f32x16_t o[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ct][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    // permuted K row for the A operand: swap bits 2 and 3 of the tile row
+    const int prow = (col & 0x13) | ((col & 4) << 1) | ((col & 8) >> 1);
+    const bool vec_v = ((T & 7) == 0);
+
+    for (int kt0 = 0; kt0 < T; kt0 += KT) {
+        __syncthreads();  // previous tile fully consumed
+        // ---- stage K tile [KT keys][CH] and V^T tile [CH][KT keys]
+        for (int pc = tid; pc < KT * (CH / 8); pc += 256) {
+            const int key = pc / (CH / 8), piece = pc % (CH / 8);
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (kt0 + key < T)
+                v = *reinterpret_cast<const uint4*>(qk + ((size_t)b * T + kt0 + key) * row2c + C + (size_t)h * CH + piece * 8);
+            *reinterpret_cast<uint4*>(k_lds + key * KP + piece * 16) = v;
+        }
+        if (vec_v) {
+            for (int pc = tid; pc < NCT * 32 * (KT / 8); pc += 256) {
+                const int c = pc / (KT / 8), piece = pc % (KT / 8);
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (c < CH && kt0 + piece * 8 < T)  // T % 8 == 0: a piece is entirely in or out
+                    v = *reinterpret_cast<const uint4*>(vt + ((size_t)b * C + (size_t)h * CH + c) * T + kt0 + piece * 8);
+                *reinterpret_cast<uint4*>(v_lds + c * VP + piece * 16) = v;
+            }
+        } else {
+            for (int e = tid; e < NCT * 32 * KT; e += 256) {
+                const int c = e / KT, key = e % KT;
+                bf16_raw v = 0;
+                if (c < CH && kt0 + key < T) v = vt[((size_t)b * C + (size_t)h * CH + c) * T + kt0 + key];
+                *reinterpret_cast<bf16_raw*>(v_lds + c * VP + key * 2) = v;
+            }
+        }
+        __syncthreads();
+
+        // ---- S^T for the two 32-key sub-tiles
+        f32x16_t s[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[u][r] = 0.0f;
+            const char* kp = k_lds + (32 * u + prow) * KP + 16 * half;
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                const uint4 a = *reinterpret_cast<const uint4*>(kp + 32 * kk);
+                s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, qf[kk]),
+                                                              s[u], 0, 0, 0);
+            }
+        }
+        // ---- online softmax (base-2), masking keys >= T
+        float mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;               // accumulator row
+                const int krow = (row & 0x13) | ((row & 4) << 1) | ((row & 8) >> 1);  // key held there (pi)
+                const int key = kt0 + 32 * u + krow;
+                const float v = (key < T) ? s[u][r] * scale_log2e : -INFINITY;
+                s[u][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);  // m_run = -inf on the first tile -> 0
+        float ps = 0.0f;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = exp2f(s[u][r] - m_new);
+                s[u][r] = pv;
+                ps += pv;
+            }
+        ps += __shfl_xor(ps, 32, 64);
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+
+        // ---- O^T += V^T * P^T : P accumulator registers 8s..8s+7 are k-step s of the B operand
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                uint4 pb;
+                pb.x = pack_bf16x2(s[u][8 * st + 0], s[u][8 * st + 1]);
+                pb.y = pack_bf16x2(s[u][8 * st + 2], s[u][8 * st + 3]);
+                pb.z = pack_bf16x2(s[u][8 * st + 4], s[u][8 * st + 5]);
+                pb.w = pack_bf16x2(s[u][8 * st + 6], s[u][8 * st + 7]);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    const uint4 a = *reinterpret_cast<const uint4*>(v_lds + (32 * ct + col) * VP + (32 * u + 16 * st + 8 * half) * 2);
+                    o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, pb),
+                                                                   o[ct], 0, 0, 0);
+                }
+            }
+    }
+
+    // ---- normalise and store: lane holds channels 32*ct + 8*rg + 4*half + {0..3} of query qi
+    if (qi < T) {
+        const float inv = 1.0f / l_run;
+        bf16_raw* op = out + ((size_t)b * T + qi) * C + (size_t)h * CH;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int c = 32 * ct + 8 * rg + 4 * half;
+                if (c < CH) {
+                    const uint2 w = make_uint2(pack_bf16x2(o[ct][4 * rg + 0] * inv, o[ct][4 * rg + 1] * inv),
+                                               pack_bf16x2(o[ct][4 * rg + 2] * inv, o[ct][4 * rg + 3] * inv));
+                    *reinterpret_cast<uint2*>(op + c) = w;
+                }
+            }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Exact-fp32 variant (parity path, UNet compute_dtype = fp32): plain FMA flash attention.
+// 64 queries per workgroup; 4 lanes share a query, each owning CH/4 channels of q and of the output.
+template <int CH, int KT>
+__global__ __launch_bounds__(256) void k_attn_f32(const float* __restrict__ qk, const float* __restrict__ vt,
+                                                  float* __restrict__ out, int T, int C, float scale_log2e) {
+    constexpr int CP = CH / 4;
+    __shared__ float k_lds[KT][CH + 1];
+    __shared__ float v_lds[KT][CH + 1];
+    const int tid = threadIdx.x, part = tid & 3;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int qi = blockIdx.x * 64 + (tid >> 2);
+    const size_t row2c = (size_t)2 * C;
+    float q[CP], o[CP];
+    {
+        const int qc = qi < T ? qi : T - 1;
+        const float* qp = qk + ((size_t)b * T + qc) * row2c + (size_t)h * CH + part * CP;
+#pragma unroll
+        for (int c = 0; c < CP; ++c) {
+            q[c] = qp[c];
+            o[c] = 0.0f;
+        }
+    }
+    float m_run = -INFINITY, l_run = 0.0f;
+    for (int kt0 = 0; kt0 < T; kt0 += KT) {
+        __syncthreads();
+        for (int e = tid; e < KT * CH; e += 256) {
+            const int key = e / CH, c = e % CH;
+            k_lds[key][c] = (kt0 + key < T) ? qk[((size_t)b * T + kt0 + key) * row2c + C + (size_t)h * CH + c] : 0.0f;
+        }
+        for (int e = tid; e < KT * CH; e += 256) {
+            const int c = e / KT, key = e % KT;
+            v_lds[key][c] = (kt0 + key < T) ? vt[((size_t)b * C + (size_t)h * CH + c) * T + kt0 + key] : 0.0f;
+        }
+        __syncthreads();
+        float sc[KT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            float d = 0.0f;
+#pragma unroll
+            for (int c = 0; c < CP; ++c) d = fmaf(q[c], k_lds[k][part * CP + c], d);
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            d = (kt0 + k < T) ? d * scale_log2e : -INFINITY;
+            sc[k] = d;
+            mx = fmaxf(mx, d);
+        }
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);
+        float ps = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CP; ++c) o[c] *= alpha;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            const float pv = exp2f(sc[k] - m_new);
+            ps += pv;
+#pragma unroll
+            for (int c = 0; c < CP; ++c) o[c] = fmaf(pv, v_lds[k][part * CP + c], o[c]);
+        }
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+    }
+    if (qi < T) {
+        const float inv = 1.0f / l_run;
+        float* op = out + ((size_t)b * T + qi) * C + (size_t)h * CH + part * CP;
+#pragma unroll
+        for (int c = 0; c < CP; ++c) op[c] = o[c] * inv;
+    }
+}
+
+extern "C" int rho_attention_fwd(const void* qk, const void* vt, void* out, int dtype, int64_t batch, int64_t t, int64_t heads,
+                                 int64_t ch, void* stream) {
+    if (!qk || !vt || !out || batch <= 0 || t <= 0 || heads <= 0) return RHO_E_ARG;
+    if (dtype != RHO_BF16 && dtype != RHO_F32) return RHO_E_ARG;
+    const int C = (int)(heads * ch);
+    const float sl2 = (float)(1.4426950408889634 / sqrt((double)ch));
+    hipStream_t st = as_stream(stream);
+    if (dtype == RHO_F32) {
+        dim3 grid((unsigned)((t + 63) / 64), (unsigned)heads, (unsigned)batch), block(256);
+#define RHO_ATT32(chv, ktv)                                                                                             \
+    case chv:                                                                                                           \
+        hipLaunchKernelGGL((k_attn_f32<chv, ktv>), grid, block, 0, st, (const float*)qk, (const float*)vt, (float*)out, \
+                           (int)t, C, sl2);                                                                             \
+        break;
+        switch (ch) {
+            RHO_ATT32(16, 64)
+            RHO_ATT32(32, 64)
+            RHO_ATT32(64, 64)
+            RHO_ATT32(128, 32)
+            RHO_ATT32(256, 16)
+            default:
+                return RHO_E_SHAPE;
+        }
+#undef RHO_ATT32
+        RHO_LAUNCH_CHECK();
+        return 0;
+    }
+    dim3 grid((unsigned)((t + 127) / 128), (unsigned)heads, (unsigned)batch), block(256);
+#define RHO_ATT(chv)                                                                                                      \
+    case chv:                                                                                                             \
+        hipLaunchKernelGGL((k_attn_bf16<chv, (chv >= 256 ? 32 : 64)>), grid, block, 0, st, (const bf16_raw*)qk,              \
+                           (const bf16_raw*)vt, (bf16_raw*)out, (int)t, C, sl2);                                          \
+        break;
+    switch (ch) {
+        RHO_ATT(16)
+        RHO_ATT(32)
+        RHO_ATT(64)
+        RHO_ATT(128)
+        RHO_ATT(256)
+        default:
+            return RHO_E_SHAPE;
+    }
+#undef RHO_ATT
+    RHO_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,45 @@
+// Shared device helpers for librho_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rho_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef unsigned short bf16_raw;  // storage type of a bfloat16
+
+#define RHO_LAUNCH_CHECK()                    \
+    do {                                      \
+        hipError_t e_ = hipGetLastError();    \
+        if (e_ != hipSuccess) return (int)e_; \
+    } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_raw v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even; a plain cast keeps NaNs NaN (v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ bf16_raw f32_to_bf16(float f) {
+    __bf16 h = (__bf16)f;
+    return *reinterpret_cast<bf16_raw*>(&h);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

@@ -1,0 +1,540 @@
+// n-D convolution (kernel 1 or 3 per axis, zero padding k/2) for channels-last activations as an
+// implicit GEMM on the CDNA4 matrix cores, designed around the 160 KiB LDS of a gfx950 CU:
+//
+//   * A workgroup (4 waves) owns an output tile of 256 positions (TD x TH x TW, chosen per layer)
+//     and BM output channels.  For each 64-byte input-channel chunk (32 bf16 / 16 f32 channels) it
+//     stages the tile's input region INCLUDING THE HALO into LDS once -- applying the folded
+//     GroupNorm+FiLM affine and SiLU on the way (unet_v2.py:212-216,285-289), zero-filling the
+//     padding AFTER the activation -- and then runs all kd*kh*kw taps out of that resident tile
+//     at shifted LDS addresses.  Global->LDS traffic is ~2.3x the input instead of 27x, the
+//     GN/SiLU work is paid 2.3x instead of 27x, and torch.cat / nearest-upsample / stride never
+//     exist as tensors: they are address arithmetic in the loader (unet_v2.py:729,122-131,153).
+//   * Orientation is D[cout][position] = W[cout][k] * X[k][position] with 32x32 MFMA tiles
+//     (v_mfma_f32_32x32x16_bf16, or the exact-f32 v_mfma_f32_32x32x2_f32): each lane ends up
+//     holding 4 consecutive output channels of ONE position, so the epilogue (bias, residual,
+//     additive embedding) writes 8/16-byte channels-last pieces with no shuffles.
+//   * LDS rows are 64 B of payload on an 80 B pitch: for ds_read_b128 the 16-byte slot index is
+//     5*row mod 16, a bijection, so 32 consecutive rows are conflict-free for every lane group.
+//   * Weights ([tap][cout][cin], prepared once) stream through a 2-deep LDS ring, one tap ahead.
+//
+// Replaces conv_nd at every call site of rho_diffusion/models/unet_v2.py (see include/rho_hip.h).
+#include "common.h"
+
+#define PITCH 80  // bytes per LDS row (64 payload + 16 pad)
+
+struct ConvK {
+    const char* x1;
+    const char* x2;
+    const float* pre_a;
+    const float* pre_b;
+    const char* w;
+    const float* bias;
+    const char* res;
+    const float* res_add;
+    char* y;
+    char* y2;
+    int c1, c2, cin;
+    int cout, coutp, split;
+    int D, H, W;     // input extents (depth carries the batch when merged)
+    int Do, Ho, Wo;  // output extents
+    long long S_in, S_out;  // positions per sample
+    int sh, sw, up_h, up_w, pre_silu, y2_f32;
+    int TD, TH, TW, ID, IH, IW, NP;
+    int tiles_h, tiles_w;
+    int res_add_stride;
+};
+
+template <typename T>
+struct ET;
+template <>
+struct ET<bf16_raw> {
+    static constexpr int CK = 32;  // channels per 64-byte chunk
+    static constexpr int PE = 8;   // elements per 16-byte piece
+};
+template <>
+struct ET<float> {
+    static constexpr int CK = 16;
+    static constexpr int PE = 4;
+};
+
+// y = act(a*x+b) on one 16-byte piece
+template <typename T>
+__device__ __forceinline__ uint4 apply_pre(uint4 v, const float* __restrict__ a, const float* __restrict__ b, int silu);
+
+template <>
+__device__ __forceinline__ uint4 apply_pre<bf16_raw>(uint4 v, const float* __restrict__ a, const float* __restrict__ b, int silu) {
+    const float4 a0 = *reinterpret_cast<const float4*>(a), a1 = *reinterpret_cast<const float4*>(a + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(b), b1 = *reinterpret_cast<const float4*>(b + 4);
+    float f[8];
+    f[0] = fmaf(a0.x, __uint_as_float(v.x << 16), b0.x);
+    f[1] = fmaf(a0.y, __uint_as_float(v.x & 0xFFFF0000u), b0.y);
+    f[2] = fmaf(a0.z, __uint_as_float(v.y << 16), b0.z);
+    f[3] = fmaf(a0.w, __uint_as_float(v.y & 0xFFFF0000u), b0.w);
+    f[4] = fmaf(a1.x, __uint_as_float(v.z << 16), b1.x);
+    f[5] = fmaf(a1.y, __uint_as_float(v.z & 0xFFFF0000u), b1.y);
+    f[6] = fmaf(a1.z, __uint_as_float(v.w << 16), b1.z);
+    f[7] = fmaf(a1.w, __uint_as_float(v.w & 0xFFFF0000u), b1.w);
+    if (silu) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
+    }
+    uint4 r;
+    r.x = pack_bf16x2(f[0], f[1]);
+    r.y = pack_bf16x2(f[2], f[3]);
+    r.z = pack_bf16x2(f[4], f[5]);
+    r.w = pack_bf16x2(f[6], f[7]);
+    return r;
+}
+
+template <>
+__device__ __forceinline__ uint4 apply_pre<float>(uint4 v, const float* __restrict__ a, const float* __restrict__ b, int silu) {
+    const float4 a0 = *reinterpret_cast<const float4*>(a);
+    const float4 b0 = *reinterpret_cast<const float4*>(b);
+    float f[4];
+    f[0] = fmaf(a0.x, __uint_as_float(v.x), b0.x);
+    f[1] = fmaf(a0.y, __uint_as_float(v.y), b0.y);
+    f[2] = fmaf(a0.z, __uint_as_float(v.z), b0.z);
+    f[3] = fmaf(a0.w, __uint_as_float(v.w), b0.w);
+    if (silu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = silu_f(f[j]);
+    }
+    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+}
+
+template <typename T>
+__device__ __forceinline__ void mma_step(const uint4& a, const uint4& b, f32x16_t& acc);
+
+template <>
+__device__ __forceinline__ void mma_step<bf16_raw>(const uint4& a, const uint4& b, f32x16_t& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_step<float>(const uint4& a, const uint4& b, f32x16_t& acc) {
+    // lanes 0-31 carry channels {0,1,2,3} of the 8-channel group, lanes 32-63 channels {4,5,6,7};
+    // MFMA #q contracts the channel pair (q, 4+q): any K permutation is valid as A and B agree.
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+
+template <typename T, int KD, int KH, int KW, int BM, int MAXP>
+__global__ __launch_bounds__(256) void k_conv(const ConvK p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CK = ET<T>::CK;
+    constexpr int PE = ET<T>::PE;
+    constexpr int NT = KD * KH * KW;
+    constexpr int MT = BM / 32;        // 32-row cout tiles per wave
+    constexpr int WROWS = (BM + 63) / 64;  // weight-tile rows per thread (64 rows x 4 pieces per pass)
+
+    char* const halo = smem;
+    char* const wbuf = smem + (size_t)p.NP * PITCH;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int piece = tid & 3;
+
+    // ---- tile coordinates
+    const int bt = blockIdx.x;
+    const int tw_i = bt % p.tiles_w;
+    const int th_i = (bt / p.tiles_w) % p.tiles_h;
+    const int td_i = bt / (p.tiles_w * p.tiles_h);
+    const int co0 = blockIdx.y * BM;
+    const int n = blockIdx.z;
+    const int od0 = td_i * p.TD, oh0 = th_i * p.TH, ow0 = tw_i * p.TW;
+    const int gd_base = od0 - (KD / 2);
+    const int gh_base = p.up_h ? (oh0 / 2 - 1) : (oh0 * p.sh - (KH / 2));
+    const int gw_base = p.up_w ? (ow0 / 2 - 1) : (ow0 * p.sw - (KW / 2));
+
+    // ---- halo slots owned by this thread: global linear input position (or -1 = zero padding,
+    //      -2 = beyond the tile) and sample index for the prologue coefficients
+    constexpr int NSMP = (KD == 3) ? 1 : MAXP;  // 3-D tiles never straddle samples: the sample is blockIdx.z
+    int spos[MAXP];
+    int ssmp[NSMP];
+    {
+        const int ihw = p.IH * p.IW;
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int hp = (tid >> 2) + 64 * i;
+            int pos = -2, smp = 0;
+            if (hp < p.NP) {
+                const int id = hp / ihw;
+                const int r = hp - id * ihw;
+                const int ih = r / p.IW;
+                const int iw = r - ih * p.IW;
+                const int gd = gd_base + id, gh = gh_base + ih, gw = gw_base + iw;
+                if (gd >= 0 && gd < p.D && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W) {
+                    pos = ((n * p.D + gd) * p.H + gh) * p.W + gw;
+                    if constexpr (KD != 3) smp = (int)((long long)pos / p.S_in);
+                } else {
+                    pos = -1;
+                }
+            }
+            spos[i] = pos;
+            if constexpr (KD != 3) ssmp[i] = smp;
+        }
+    }
+
+    // ---- per-lane LDS byte offsets of the B (activation) fragments, per column tile and tap axis
+    int offd[2], offh[2][KH], offw[2][KW];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pp = wave * 64 + j * 32 + (lane & 31);
+        const int pw = pp % p.TW;
+        const int ph = (pp / p.TW) % p.TH;
+        const int pd = pp / (p.TW * p.TH);
+        offd[j] = pd * p.IH * p.IW * PITCH + 16 * half;
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) {
+            const int ih = p.up_h ? (((ph + kh - 1) >> 1) + 1) : (ph * p.sh + kh);
+            offh[j][kh] = ih * p.IW * PITCH;
+        }
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) {
+            const int iw = p.up_w ? (((pw + kw - 1) >> 1) + 1) : (pw * p.sw + kw);
+            offw[j][kw] = iw * PITCH;
+        }
+    }
+    const int a_off = (lane & 31) * PITCH + 16 * half;
+
+    f32x16_t acc[MT][2];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][j][r] = 0.0f;
+
+    const int nck = p.cin / CK;
+    const size_t wrow_bytes = (size_t)p.cin * sizeof(T);
+
+    // weight tile: BM rows x 4 pieces of 16 B; thread -> row (tid>>2) + 64*k, piece tid&3.
+    // (plain scalars, no arrays by reference: those end up in scratch)
+    const bool w_active = (BM >= 64) || (tid < BM * 4);
+    const char* const w_src0 = p.w + ((size_t)co0 + (tid >> 2)) * wrow_bytes + piece * 16;
+    const size_t w_tap_stride = (size_t)p.coutp * wrow_bytes;
+    const int w_dst0 = (tid >> 2) * PITCH + piece * 16;
+    uint4 wreg0 = make_uint4(0u, 0u, 0u, 0u), wreg1 = make_uint4(0u, 0u, 0u, 0u);
+#define RHO_LOAD_W(ck_, tap_)                                                                        \
+    do {                                                                                             \
+        const char* ws_ = w_src0 + (size_t)(tap_) * w_tap_stride + (size_t)(ck_) * 64;               \
+        if (w_active) wreg0 = *reinterpret_cast<const uint4*>(ws_);                                  \
+        if constexpr (WROWS == 2) wreg1 = *reinterpret_cast<const uint4*>(ws_ + 64 * wrow_bytes);    \
+    } while (0)
+#define RHO_STORE_W(buf_)                                                                            \
+    do {                                                                                             \
+        char* wd_ = wbuf + (size_t)(buf_) * BM * PITCH + w_dst0;                                     \
+        if (w_active) *reinterpret_cast<uint4*>(wd_) = wreg0;                                        \
+        if constexpr (WROWS == 2) *reinterpret_cast<uint4*>(wd_ + 64 * PITCH) = wreg1;               \
+    } while (0)
+
+    RHO_LOAD_W(0, 0);
+    RHO_STORE_W(0);
+    int cur = 0;
+
+    for (int ck = 0; ck < nck; ++ck) {
+        // ---- stage the halo tile of this channel chunk (previous chunk's reads are fenced by the
+        //      barrier that closed its last tap)
+        {
+            const int c = ck * CK;
+            const char* src;
+            int cs, csrc;
+            if (c < p.c1) {
+                src = p.x1;
+                cs = p.c1;
+                csrc = c;
+            } else {
+                src = p.x2;
+                cs = p.c2;
+                csrc = c - p.c1;
+            }
+            constexpr int GB = (MAXP % 7 == 0) ? 7 : 5;  // loads in flight per batch (divides MAXP)
+#pragma unroll
+            for (int i0 = 0; i0 < MAXP; i0 += GB) {
+                uint4 v[GB];
+#pragma unroll
+                for (int q = 0; q < GB; ++q) {
+                    const int i = i0 + q;
+                    if (i < MAXP) {
+                        v[q] = make_uint4(0u, 0u, 0u, 0u);
+                        if (spos[i] >= 0)
+                            v[q] = *reinterpret_cast<const uint4*>(src + ((size_t)spos[i] * cs + csrc) * sizeof(T) + piece * 16);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < GB; ++q) {
+                    const int i = i0 + q;
+                    if (i < MAXP) {
+                        if (spos[i] != -2) {
+                            uint4 u = v[q];
+                            if (p.pre_a != nullptr && spos[i] >= 0) {
+                                const int smp = (KD == 3) ? n : ssmp[(KD == 3) ? 0 : i];
+                                const size_t co = (size_t)smp * p.cin + c + piece * PE;
+                                u = apply_pre<T>(u, p.pre_a + co, p.pre_b + co, p.pre_silu);
+                            }
+                            const int hp = (tid >> 2) + 64 * i;
+                            *reinterpret_cast<uint4*>(halo + hp * PITCH + piece * 16) = u;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- all taps out of the resident tile
+#pragma unroll
+        for (int kd = 0; kd < KD; ++kd) {
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh) {
+#pragma unroll
+                for (int kw = 0; kw < KW; ++kw) {
+                    const int tap = (kd * KH + kh) * KW + kw;
+                    const bool has_next = !(ck == nck - 1 && tap == NT - 1);
+                    if (has_next) {
+                        const int ntap = (tap == NT - 1) ? 0 : tap + 1;
+                        const int nckk = (tap == NT - 1) ? ck + 1 : ck;
+                        RHO_LOAD_W(nckk, ntap);
+                    }
+                    const char* wcur = wbuf + (size_t)cur * BM * PITCH + a_off;
+                    const int dtap = kd * p.IH * p.IW * PITCH;
+                    const char* b0p = halo + (dtap + offd[0] + offh[0][kh] + offw[0][kw]);
+                    const char* b1p = halo + (dtap + offd[1] + offh[1][kh] + offw[1][kw]);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const uint4 b0 = *reinterpret_cast<const uint4*>(b0p + 32 * s);
+                        const uint4 b1 = *reinterpret_cast<const uint4*>(b1p + 32 * s);
+#pragma unroll
+                        for (int mi = 0; mi < MT; ++mi) {
+                            const uint4 a = *reinterpret_cast<const uint4*>(wcur + mi * 32 * PITCH + 32 * s);
+                            mma_step<T>(a, b0, acc[mi][0]);
+                            mma_step<T>(a, b1, acc[mi][1]);
+                        }
+                    }
+                    if (has_next) RHO_STORE_W(cur ^ 1);
+                    __syncthreads();
+                    cur ^= 1;
+                }
+            }
+        }
+    }
+
+#undef RHO_LOAD_W
+#undef RHO_STORE_W
+    // ---- epilogue: lane holds, for position column (lane&31) of tile j, channels
+    //      co0 + 32*mi + 8*rg + 4*half + {0,1,2,3}  in acc[mi][j][4*rg + {0..3}]
+    const bool cl_region = (co0 < p.split);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pp = wave * 64 + j * 32 + (lane & 31);
+        const int pw = pp % p.TW;
+        const int ph = (pp / p.TW) % p.TH;
+        const int pd = pp / (p.TW * p.TH);
+        const int od = od0 + pd, oh = oh0 + ph, ow = ow0 + pw;
+        if (od >= p.Do || oh >= p.Ho || ow >= p.Wo) continue;
+        const long long L = (((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
+        const long long ns = L / p.S_out;
+        const long long ps = L - ns * p.S_out;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int co = co0 + mi * 32 + rg * 8 + half * 4;
+                const float4 bv = *reinterpret_cast<const float4*>(p.bias + co);
+                float v0 = acc[mi][j][rg * 4 + 0] + bv.x;
+                float v1 = acc[mi][j][rg * 4 + 1] + bv.y;
+                float v2 = acc[mi][j][rg * 4 + 2] + bv.z;
+                float v3 = acc[mi][j][rg * 4 + 3] + bv.w;
+                if (cl_region) {
+                    if (p.res_add != nullptr) {
+                        const float4 e = *reinterpret_cast<const float4*>(p.res_add + ns * p.res_add_stride + co);
+                        v0 += e.x; v1 += e.y; v2 += e.z; v3 += e.w;
+                    }
+                    const size_t eo = (size_t)L * p.split + co;
+                    if constexpr (sizeof(T) == 2) {
+                        if (p.res != nullptr) {
+                            const uint2 r = *reinterpret_cast<const uint2*>(p.res + eo * 2);
+                            v0 += __uint_as_float(r.x << 16); v1 += __uint_as_float(r.x & 0xFFFF0000u);
+                            v2 += __uint_as_float(r.y << 16); v3 += __uint_as_float(r.y & 0xFFFF0000u);
+                        }
+                        *reinterpret_cast<uint2*>(p.y + eo * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                    } else {
+                        if (p.res != nullptr) {
+                            const float4 r = *reinterpret_cast<const float4*>(p.res + eo * 4);
+                            v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
+                        }
+                        *reinterpret_cast<float4*>(p.y + eo * 4) = make_float4(v0, v1, v2, v3);
+                    }
+                } else {
+                    const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (co + e < p.cout) {
+                            const size_t eo = ((size_t)ns * (p.cout - p.split) + (co + e - p.split)) * p.S_out + ps;
+                            if (p.y2_f32 || sizeof(T) == 4)
+                                reinterpret_cast<float*>(p.y2)[eo] = vv[e];
+                            else
+                                reinterpret_cast<bf16_raw*>(p.y2)[eo] = f32_to_bf16(vv[e]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host
+namespace {
+
+struct TileChoice {
+    int TD, TH, TW, ID, IH, IW, NP;
+    long long tiles;
+    bool ok;
+};
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// pick the 256-position output tile: fewest tiles first, then the smallest halo, then the widest W
+TileChoice choose_tile(const rho_conv_desc& d, int Dm, int Do, int Ho, int Wo, int np_cap) {
+    TileChoice best{};
+    best.ok = false;
+    double best_cost = 1e300;
+    for (int TD = 1; TD <= 256; TD *= 2)
+        for (int TH = 1; TH * TD <= 256; TH *= 2) {
+            const int TW = 256 / (TD * TH);
+            if (d.up_h && TH < 2) continue;
+            if (d.up_w && TW < 2) continue;
+            const int ID = TD + (d.kd - 1);
+            const int IH = d.up_h ? TH / 2 + 2 : (TH - 1) * d.sh + d.kh;
+            const int IW = d.up_w ? TW / 2 + 2 : (TW - 1) * d.sw + d.kw;
+            const int NP = ID * IH * IW;
+            if (NP > np_cap) continue;
+            const long long tiles = (long long)cdiv(Do, TD) * cdiv(Ho, TH) * cdiv(Wo, TW);
+            // cost model: per tile, staging ~ NP rows and taps*256 MFMA columns
+            const double cost = (double)tiles * (NP * 1.5 + 256.0 * d.kd * d.kh * d.kw) - 1e-3 * TW;
+            if (cost < best_cost) {
+                best_cost = cost;
+                best = TileChoice{TD, TH, TW, ID, IH, IW, NP, tiles, true};
+            }
+        }
+    (void)Dm;
+    return best;
+}
+
+template <typename T, int KD, int KH, int KW, int BM, int MAXP>
+int launch_one(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
+    auto fn = k_conv<T, KD, KH, KW, BM, MAXP>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, k);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+template <typename T, int KD, int KH, int KW>
+int launch_bm(const ConvK& k, int BM, int maxp, dim3 grid, size_t lds, hipStream_t st) {
+#define RHO_CASE(bm)                                                                \
+    if (BM == bm) {                                                                 \
+        if (maxp <= 10) return launch_one<T, KD, KH, KW, bm, 10>(k, grid, lds, st); \
+        return launch_one<T, KD, KH, KW, bm, 28>(k, grid, lds, st);                 \
+    }
+    RHO_CASE(32)
+    RHO_CASE(64)
+    RHO_CASE(128)
+#undef RHO_CASE
+    return RHO_E_ARG;
+}
+
+template <typename T>
+int launch_taps(const rho_conv_desc& d, const ConvK& k, int BM, int maxp, dim3 grid, size_t lds, hipStream_t st) {
+    if (d.kd == 3 && d.kh == 3 && d.kw == 3) return launch_bm<T, 3, 3, 3>(k, BM, maxp, grid, lds, st);
+    if (d.kd == 1 && d.kh == 3 && d.kw == 3) return launch_bm<T, 1, 3, 3>(k, BM, maxp, grid, lds, st);
+    if (d.kd == 1 && d.kh == 1 && d.kw == 3) return launch_bm<T, 1, 1, 3>(k, BM, maxp, grid, lds, st);
+    if (d.kd == 1 && d.kh == 1 && d.kw == 1) return launch_bm<T, 1, 1, 1>(k, BM, maxp, grid, lds, st);
+    return RHO_E_ARG;
+}
+
+}  // namespace
+
+extern "C" int rho_conv_nd_fwd(const rho_conv_desc* dp, void* stream) {
+    if (!dp) return RHO_E_ARG;
+    const rho_conv_desc& d = *dp;
+    if (!d.x1 || !d.w || !d.bias) return RHO_E_ARG;
+    if (d.dtype != RHO_F32 && d.dtype != RHO_BF16) return RHO_E_ARG;
+    const int CK = d.dtype == RHO_BF16 ? 32 : 16;
+    const int c2 = d.x2 ? d.c2 : 0;
+    const int cin = d.c1 + c2;
+    if (d.c1 <= 0 || d.c1 % CK || c2 % CK) return RHO_E_ALIGN;
+    if (d.cout <= 0 || d.coutp < d.cout || d.coutp % 32 || d.split < 0 || d.split > d.cout || d.split % 32) return RHO_E_ARG;
+    if (d.split > 0 && !d.y) return RHO_E_ARG;
+    if (d.split < d.cout && !d.y2) return RHO_E_ARG;
+    if (d.split < d.cout && d.split > 0 && d.coutp != d.cout) return RHO_E_ARG;  // mixed layouts need exact tiling
+    if (d.split == d.cout && d.coutp != d.cout) return RHO_E_ARG;               // channels-last rows are not padded
+    if ((d.sh != 1 && d.sh != 2) || (d.sw != 1 && d.sw != 2)) return RHO_E_ARG;
+    if ((d.up_h && d.sh != 1) || (d.up_w && d.sw != 1)) return RHO_E_ARG;
+    if ((d.up_h && d.kh != 3) || (d.up_w && d.kw != 3)) return RHO_E_ARG;
+    if (d.n <= 0 || d.d <= 0 || d.h <= 0 || d.w_ <= 0) return RHO_E_ARG;
+
+    // output extents per sample (padding k/2)
+    const int ho = d.up_h ? d.h * 2 : (d.h + 2 * (d.kh / 2) - d.kh) / d.sh + 1;
+    const int wo = d.up_w ? d.w_ * 2 : (d.w_ + 2 * (d.kw / 2) - d.kw) / d.sw + 1;
+    const int dout = d.d;
+
+    // axes that carry no kernel extent are merged with the batch so tiles stay full:
+    //   1x1x1: everything is one long W axis;  1xkxk: depth*batch is the tile's depth axis.
+    ConvK k{};
+    int gridz = d.n;
+    if (d.kd == 1 && d.kh == 1 && d.kw == 1) {
+        if (d.sh != 1 || d.sw != 1 || d.up_h || d.up_w) return RHO_E_ARG;
+        k.D = 1; k.H = 1; k.W = d.n * d.d * d.h * d.w_;
+        k.Do = 1; k.Ho = 1; k.Wo = k.W;
+        gridz = 1;
+    } else if (d.kd == 1) {
+        k.D = d.n * d.d; k.H = d.h; k.W = d.w_;
+        k.Do = k.D; k.Ho = ho; k.Wo = wo;
+        gridz = 1;
+    } else {
+        k.D = d.d; k.H = d.h; k.W = d.w_;
+        k.Do = dout; k.Ho = ho; k.Wo = wo;
+    }
+    if ((long long)d.n * d.d * d.h * d.w_ >= (1LL << 31) || (long long)d.n * dout * ho * wo >= (1LL << 31)) return RHO_E_SHAPE;
+    k.S_in = (long long)d.d * d.h * d.w_;
+    k.S_out = (long long)dout * ho * wo;
+
+    // cout tile
+    int BM = 32;
+    if (d.coutp % 128 == 0 && (d.split % 128 == 0)) BM = 128;
+    else if (d.coutp % 64 == 0 && (d.split % 64 == 0)) BM = 64;
+
+    const size_t lds_cap = 160 * 1024;
+    int np_cap = (int)((lds_cap - 2 * (size_t)BM * PITCH) / PITCH);
+    if (np_cap > 28 * 64) np_cap = 28 * 64;
+    // prefer the small-halo (2 blocks / CU) configuration when it exists
+    TileChoice t = choose_tile(d, k.D, k.Do, k.Ho, k.Wo, 640);
+    if (!t.ok) t = choose_tile(d, k.D, k.Do, k.Ho, k.Wo, np_cap);
+    if (!t.ok) return RHO_E_SHAPE;
+
+    k.x1 = (const char*)d.x1; k.x2 = (const char*)d.x2; k.pre_a = d.pre_a; k.pre_b = d.pre_b;
+    k.w = (const char*)d.w; k.bias = d.bias; k.res = (const char*)d.res; k.res_add = d.res_add;
+    k.y = (char*)d.y; k.y2 = (char*)d.y2;
+    k.c1 = d.c1; k.c2 = c2; k.cin = cin;
+    k.cout = d.cout; k.coutp = d.coutp; k.split = d.split;
+    k.res_add_stride = d.res_add_stride > 0 ? d.res_add_stride : d.split;
+    k.sh = d.sh; k.sw = d.sw; k.up_h = d.up_h; k.up_w = d.up_w; k.pre_silu = d.pre_silu; k.y2_f32 = d.y2_f32;
+    k.TD = t.TD; k.TH = t.TH; k.TW = t.TW; k.ID = t.ID; k.IH = t.IH; k.IW = t.IW; k.NP = t.NP;
+    k.tiles_h = cdiv(k.Ho, t.TH); k.tiles_w = cdiv(k.Wo, t.TW);
+    if (d.pre_a && !d.pre_b) return RHO_E_ARG;
+
+    const long long tiles = (long long)cdiv(k.Do, t.TD) * k.tiles_h * k.tiles_w;
+    if (tiles > 0x7FFFFFFFLL || d.coutp / BM > 65535 || gridz > 65535) return RHO_E_SHAPE;
+    dim3 grid((unsigned)tiles, (unsigned)(d.coutp / BM), (unsigned)gridz);
+    const size_t lds = (size_t)t.NP * PITCH + 2 * (size_t)BM * PITCH;
+    const int maxp = cdiv(t.NP, 64);
+    hipStream_t st = as_stream(stream);
+    if (d.dtype == RHO_BF16) return launch_taps<bf16_raw>(d, k, BM, maxp, grid, lds, st);
+    return launch_taps<float>(d, k, BM, maxp, grid, lds, st);
+}

@@ -1,0 +1,378 @@
+// HBM-bound kernels of the DDPM loops and the small embedding GEMVs.
+// Each kernel is a grid-stride loop over 16-byte-per-lane accesses (coalesced 1 KiB per wave
+// instruction), grid capped at 256 CUs x 8 blocks.
+#include "common.h"
+
+static inline int grid_for(int64_t work_items, int block) {
+    int64_t g = (work_items + block - 1) / block;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" int rho_abi_version(void) { return 1; }
+extern "C" const char* rho_build_info(void) { return "librho_hip gfx950 (CDNA4) hipcc -O3; MFMA 32x32x16 bf16 / 32x32x2 f32"; }
+
+// ----------------------------------------------------------------------------- q_sample
+// ddpm.py:122-129: x_t = sqrt(abar_t)*x0 + sqrt(1-abar_t)*eps, abar gathered per batch element.
+__global__ __launch_bounds__(256) void k_q_sample(const float4* __restrict__ x0, const float4* __restrict__ eps,
+                                                  float4* __restrict__ xt, const float* __restrict__ abar,
+                                                  const int64_t* __restrict__ t, int64_t per4, int64_t total4,
+                                                  int32_t* nan_flag) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / per4;
+        const float ab = abar[t[b]];
+        const float sa = sqrtf(ab), sb = sqrtf(1.0f - ab);
+        const float4 a = x0[i], e = eps[i];
+        float4 r;
+        r.x = sa * a.x + sb * e.x;
+        r.y = sa * a.y + sb * e.y;
+        r.z = sa * a.z + sb * e.z;
+        r.w = sa * a.w + sb * e.w;
+        bad |= (r.x != r.x) | (r.y != r.y) | (r.z != r.z) | (r.w != r.w);
+        xt[i] = r;
+    }
+    if (nan_flag != nullptr && __any(bad)) {
+        if ((threadIdx.x & 63) == 0) atomicOr(nan_flag, 1);
+    }
+}
+
+__global__ void k_q_sample_tail(const float* x0, const float* eps, float* xt, const float* abar, const int64_t* t,
+                                int64_t per_sample, int64_t batch, int64_t tail_start, int32_t* nan_flag) {
+    // scalar path for per_sample % 4 != 0 (only tiny test shapes)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < batch * per_sample; i += (int64_t)gridDim.x * blockDim.x) {
+        const float ab = abar[t[i / per_sample]];
+        const float r = sqrtf(ab) * x0[i] + sqrtf(1.0f - ab) * eps[i];
+        if (r != r && nan_flag) atomicOr(nan_flag, 1);
+        xt[i] = r;
+    }
+}
+
+extern "C" int rho_q_sample(const float* x0, const float* eps, float* x_t, const float* alpha_bar, const int64_t* t,
+                            int64_t batch, int64_t per_sample, int32_t* nan_flag, void* stream) {
+    if (!x0 || !eps || !x_t || !alpha_bar || !t || batch <= 0 || per_sample <= 0) return RHO_E_ARG;
+    if (per_sample % 4 == 0 && (((uintptr_t)x0 | (uintptr_t)eps | (uintptr_t)x_t) & 15) == 0) {
+        const int64_t total4 = batch * per_sample / 4;
+        hipLaunchKernelGGL(k_q_sample, dim3(grid_for(total4, 256)), dim3(256), 0, as_stream(stream), (const float4*)x0,
+                           (const float4*)eps, (float4*)x_t, alpha_bar, t, per_sample / 4, total4, nan_flag);
+    } else {
+        hipLaunchKernelGGL(k_q_sample_tail, dim3(grid_for(batch * per_sample, 256)), dim3(256), 0, as_stream(stream), x0, eps,
+                           x_t, alpha_bar, t, per_sample, batch, (int64_t)0, nan_flag);
+    }
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
+// ----------------------------------------------------------------------------- p_sample_step
+// ddpm.py:210-218.  coef row = {1/sqrt(alpha), beta/sqrt(1-abar), 0.8*sqrt(beta)}; t read on device so
+// that one captured graph serves every step; t == 0 => no update (q3), t <= 1 => z ignored.
+__global__ __launch_bounds__(256) void k_p_sample(float* __restrict__ x, const float* __restrict__ eh,
+                                                  const float* __restrict__ z, const float* __restrict__ coef,
+                                                  const int32_t* __restrict__ t_dev, int64_t n) {
+    const int t = *t_dev;
+    if (t <= 0) return;
+    const float c0 = coef[3 * t + 0], c1 = coef[3 * t + 1], c2 = (t > 1 && z != nullptr) ? coef[3 * t + 2] : 0.0f;
+    const int64_t n4 = n >> 2;
+    const bool vec = ((((uintptr_t)x | (uintptr_t)eh | (uintptr_t)z) & 15) == 0);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        float4* x4 = (float4*)x;
+        const float4* e4 = (const float4*)eh;
+        const float4* z4 = (const float4*)z;
+        for (int64_t i = tid; i < n4; i += stride) {
+            float4 a = x4[i];
+            const float4 e = e4[i];
+            float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c2 != 0.0f) zz = z4[i];
+            a.x = fminf(fmaxf(c0 * (a.x - c1 * e.x) + c2 * zz.x, -1.0f), 1.0f);
+            a.y = fminf(fmaxf(c0 * (a.y - c1 * e.y) + c2 * zz.y, -1.0f), 1.0f);
+            a.z = fminf(fmaxf(c0 * (a.z - c1 * e.z) + c2 * zz.z, -1.0f), 1.0f);
+            a.w = fminf(fmaxf(c0 * (a.w - c1 * e.w) + c2 * zz.w, -1.0f), 1.0f);
+            x4[i] = a;
+        }
+        for (int64_t i = (n4 << 2) + tid; i < n; i += stride) {
+            const float zz = (c2 != 0.0f) ? z[i] : 0.0f;
+            x[i] = fminf(fmaxf(c0 * (x[i] - c1 * eh[i]) + c2 * zz, -1.0f), 1.0f);
+        }
+    } else {
+        for (int64_t i = tid; i < n; i += stride) {
+            const float zz = (c2 != 0.0f) ? z[i] : 0.0f;
+            x[i] = fminf(fmaxf(c0 * (x[i] - c1 * eh[i]) + c2 * zz, -1.0f), 1.0f);
+        }
+    }
+}
+
+extern "C" int rho_p_sample_step(float* x, const float* eps_hat, const float* z, const float* coef_table,
+                                 const int32_t* t_dev, int64_t n, void* stream) {
+    if (!x || !eps_hat || !coef_table || !t_dev || n <= 0) return RHO_E_ARG;
+    hipLaunchKernelGGL(k_p_sample, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, as_stream(stream), x, eps_hat, z, coef_table,
+                       t_dev, n);
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
+// t <- t - 1 and philox offset += delta: keeps the sampling loop's step state on the device
+__global__ void k_step_advance(int32_t* t_dev, uint64_t* offset_dev, uint64_t delta) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (t_dev) *t_dev -= 1;
+        if (offset_dev) *offset_dev += delta;
+    }
+}
+extern "C" int rho_step_advance(int32_t* t_dev, uint64_t* offset_dev, uint64_t delta, void* stream) {
+    hipLaunchKernelGGL(k_step_advance, dim3(1), dim3(64), 0, as_stream(stream), t_dev, offset_dev, delta);
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
+// ----------------------------------------------------------------------------- Philox4x32-10 normals
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__device__ __forceinline__ void philox4x32_10(uint64_t ctr, uint64_t seed, uint32_t (&out)[4]) {
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+__device__ __forceinline__ void box_muller(uint32_t u0, uint32_t u1, float& a, float& b) {
+    const float f0 = ((float)(u0 >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
+    const float f1 = ((float)(u1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float r = sqrtf(-2.0f * __logf(f0));
+    float s, c;
+    __sincosf(6.283185307179586f * f1, &s, &c);
+    a = r * c;
+    b = r * s;
+}
+
+__global__ __launch_bounds__(256) void k_philox_normal(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset,
+                                                       const uint64_t* __restrict__ offset_dev) {
+    const uint64_t base = offset_dev ? *offset_dev : offset;
+    const int64_t n4 = (n + 3) >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t r[4];
+        philox4x32_10(base + (uint64_t)i, seed, r);
+        float v[4];
+        box_muller(r[0], r[1], v[0], v[1]);
+        box_muller(r[2], r[3], v[2], v[3]);
+        const int64_t e = i << 2;
+        if (e + 3 < n && (((uintptr_t)out & 15) == 0)) {
+            *reinterpret_cast<float4*>(out + e) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            for (int k = 0; k < 4; ++k)
+                if (e + k < n) out[e + k] = v[k];
+        }
+    }
+}
+
+extern "C" int rho_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, void* stream) {
+    if (!out || n <= 0) return RHO_E_ARG;
+    hipLaunchKernelGGL(k_philox_normal, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, as_stream(stream), out, n, seed, offset,
+                       offset_dev);
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
+// ----------------------------------------------------------------------------- MSE (+grad)
+__global__ __launch_bounds__(256) void k_mse(const float* __restrict__ a, const float* __restrict__ b, float* loss,
+                                             float* __restrict__ grad, int64_t n, float inv_n) {
+    __shared__ float red[4];
+    float acc = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = a[i] - b[i];
+        acc += d * d;
+        if (grad) grad[i] = 2.0f * d * inv_n;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_n);
+}
+
+extern "C" int rho_mse(const float* a, const float* b, float* loss, float* grad_a, int64_t n, void* stream) {
+    if (!a || !b || !loss || n <= 0) return RHO_E_ARG;
+    hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), as_stream(stream));
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_mse, dim3(grid_for(n, 256 * 8)), dim3(256), 0, as_stream(stream), a, b, loss, grad_a, n, 1.0f / (float)n);
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
+// ----------------------------------------------------------------------------- AdamW
+__global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                               float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                               float wd, float bc1, float rsqrt_bc2) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
+        pi -= (lr / bc1) * (mi / denom);
+        p[i] = pi;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+extern "C" int rho_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                         float eps, float weight_decay, int32_t step, void* stream) {
+    if (!p || !g || !m || !v || n <= 0 || step < 1) return RHO_E_ARG;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(k_adamw, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, beta1, beta2, eps,
+                       weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)));
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
+// ----------------------------------------------------------------------------- embeddings
+__global__ void k_embed_gather(const float* __restrict__ table, const int64_t* __restrict__ t,
+                               const int32_t* __restrict__ t_scalar, float* __restrict__ out, int64_t batch, int64_t dim,
+                               int64_t rows) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch * dim) return;
+    const int64_t b = i / dim, d = i % dim;
+    int64_t row = t_scalar ? (int64_t)(*t_scalar) : t[b];
+    row = row < 0 ? 0 : (row >= rows ? rows - 1 : row);
+    out[i] = table[row * dim + d];
+}
+
+extern "C" int rho_embed_gather(const float* table, const int64_t* t, const int32_t* t_scalar_dev, float* out,
+                                int64_t batch, int64_t dim, int64_t rows, void* stream) {
+    if (!table || !out || (!t && !t_scalar_dev) || batch <= 0 || dim <= 0 || rows <= 0) return RHO_E_ARG;
+    hipLaunchKernelGGL(k_embed_gather, dim3((unsigned)((batch * dim + 255) / 256)), dim3(256), 0, as_stream(stream), table, t,
+                       t_scalar_dev, out, batch, dim, rows);
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
+// One wave per output feature: the weight row stays in registers while the wave walks the batch.
+// (B <= a few hundred, in_dim <= 1024: launch-latency bound)
+template <int MAXK>  // in_dim <= 64*MAXK
+__global__ __launch_bounds__(256) void k_linear(const float* __restrict__ x, const float* __restrict__ w,
+                                                const float* __restrict__ bias, const float* __restrict__ add,
+                                                float* __restrict__ out, int batch, int in_dim, int out_dim, int act_in,
+                                                int act_out) {
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= out_dim) return;
+    float wr[MAXK];
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) {
+        const int k = lane + 64 * j;
+        wr[j] = (k < in_dim) ? w[(int64_t)o * in_dim + k] : 0.0f;
+    }
+    const float bo = bias ? bias[o] : 0.0f;
+    for (int b = 0; b < batch; ++b) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < MAXK; ++j) {
+            const int k = lane + 64 * j;
+            if (k < in_dim) {
+                float xv = x[(int64_t)b * in_dim + k];
+                if (act_in) xv = xv / (1.0f + expf(-xv));
+                acc = fmaf(xv, wr[j], acc);
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            float r = acc + bo;
+            if (add) r += add[(int64_t)b * out_dim + o];
+            if (act_out) r = r / (1.0f + expf(-r));
+            out[(int64_t)b * out_dim + o] = r;
+        }
+    }
+}
+
+extern "C" int rho_linear(const float* x, const float* w, const float* bias, const float* add, float* out, int64_t batch,
+                          int64_t in_dim, int64_t out_dim, int act_in, int act_out, void* stream) {
+    if (!x || !w || !out || batch <= 0 || in_dim <= 0 || out_dim <= 0 || in_dim > 2048) return RHO_E_ARG;
+    dim3 grid((unsigned)((out_dim + 3) / 4)), block(256);
+    if (in_dim <= 256)
+        hipLaunchKernelGGL(k_linear<4>, grid, block, 0, as_stream(stream), x, w, bias, add, out, (int)batch, (int)in_dim,
+                           (int)out_dim, act_in, act_out);
+    else if (in_dim <= 1024)
+        hipLaunchKernelGGL(k_linear<16>, grid, block, 0, as_stream(stream), x, w, bias, add, out, (int)batch, (int)in_dim,
+                           (int)out_dim, act_in, act_out);
+    else
+        hipLaunchKernelGGL(k_linear<32>, grid, block, 0, as_stream(stream), x, w, bias, add, out, (int)batch, (int)in_dim,
+                           (int)out_dim, act_in, act_out);
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
+// ----------------------------------------------------------------------------- layout
+template <typename T>
+__device__ __forceinline__ T cvt_out(float v);
+template <>
+__device__ __forceinline__ float cvt_out<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ bf16_raw cvt_out<bf16_raw>(float v) { return f32_to_bf16(v); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack_input(const float* __restrict__ x, T* __restrict__ y, int64_t n, int64_t c,
+                                                    int64_t s, int64_t cpad) {
+    // thread per (sample, position): channel reads are coalesced across the wave for each c
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * s; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / s, p = i % s;
+        T* dst = y + i * cpad;
+        for (int64_t ch = 0; ch < cpad; ++ch) dst[ch] = cvt_out<T>(ch < c ? x[(b * c + ch) * s + p] : 0.0f);
+    }
+}
+
+extern "C" int rho_pack_input(const float* x, void* y, int dtype, int64_t n, int64_t c, int64_t s, int64_t cpad, void* stream) {
+    if (!x || !y || n <= 0 || c <= 0 || s <= 0 || cpad < c) return RHO_E_ARG;
+    dim3 grid(grid_for(n * s, 256)), block(256);
+    if (dtype == RHO_BF16)
+        hipLaunchKernelGGL(k_pack_input<bf16_raw>, grid, block, 0, as_stream(stream), x, (bf16_raw*)y, n, c, s, cpad);
+    else if (dtype == RHO_F32)
+        hipLaunchKernelGGL(k_pack_input<float>, grid, block, 0, as_stream(stream), x, (float*)y, n, c, s, cpad);
+    else
+        return RHO_E_ARG;
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_prep_w(const float* __restrict__ w, T* __restrict__ out, int64_t cout, int64_t cin,
+                                                int64_t taps, int64_t coutp, int64_t cinp, const int32_t* __restrict__ row_src) {
+    const int64_t total = taps * coutp * cinp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t ci = i % cinp;
+        const int64_t co = (i / cinp) % coutp;
+        const int64_t tap = i / (cinp * coutp);
+        int64_t src = row_src ? (int64_t)row_src[co] : (co < cout ? co : -1);
+        float v = 0.0f;
+        if (src >= 0 && src < cout && ci < cin) v = w[(src * cin + ci) * taps + tap];
+        out[i] = cvt_out<T>(v);
+    }
+}
+
+extern "C" int rho_prep_conv_weight(const float* w, void* out, int dtype, int64_t cout, int64_t cin, int64_t taps,
+                                    int64_t coutp, int64_t cinp, const int32_t* row_src, void* stream) {
+    if (!w || !out || cout <= 0 || cin <= 0 || taps <= 0 || cinp < cin || (!row_src && coutp < cout)) return RHO_E_ARG;
+    dim3 grid(grid_for(taps * coutp * cinp, 256)), block(256);
+    if (dtype == RHO_BF16)
+        hipLaunchKernelGGL(k_prep_w<bf16_raw>, grid, block, 0, as_stream(stream), w, (bf16_raw*)out, cout, cin, taps, coutp, cinp, row_src);
+    else if (dtype == RHO_F32)
+        hipLaunchKernelGGL(k_prep_w<float>, grid, block, 0, as_stream(stream), w, (float*)out, cout, cin, taps, coutp, cinp, row_src);
+    else
+        return RHO_E_ARG;
+    RHO_LAUNCH_CHECK();
+    return 0;
+}

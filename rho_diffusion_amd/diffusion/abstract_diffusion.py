@@ -1,0 +1,126 @@
+"""Pipeline base class (reference: rho_diffusion/diffusion/abstract_diffusion.py:51-276).
+
+Same constructor contract (backbone / cond_fn / optimizer resolved by registry name), same helper
+methods.  Lightning is optional: when ``lightning`` is importable the class is a LightningModule
+(so ``Trainer.fit`` works as in scripts/training.py); otherwise a minimal stand-in supplies the
+attributes the pipelines use (``log``, ``device``, ``global_rank``, ``current_epoch``, ``hparams``).
+"""
+from __future__ import annotations
+
+import math
+import types
+from inspect import getfullargspec
+from logging import getLogger
+from typing import Any, Mapping, Union
+
+import torch
+from torch import Tensor, nn
+from torch.optim import AdamW
+
+from ..registry import registry
+
+try:  # pragma: no cover - lightning is not installed in the build container
+    from lightning import pytorch as pl
+    _Base = pl.LightningModule
+except Exception:  # noqa: BLE001
+    class _Base(nn.Module):
+        """LightningModule stand-in (attribute surface only)."""
+
+        def __init__(self):
+            super().__init__()
+            self.hparams = types.SimpleNamespace()
+            self.global_rank = int(__import__("os").environ.get("RANK", "0"))
+            self.current_epoch = 0
+            self._logged = {}
+
+        def save_hyperparameters(self, d):
+            for k, v in d.items():
+                setattr(self.hparams, k, v)
+
+        def log(self, name, value, **kwargs):
+            self._logged[name] = value
+
+        @property
+        def device(self):
+            try:
+                return next(self.parameters()).device
+            except StopIteration:
+                return torch.device("cpu")
+
+__all__ = ["AbstractDiffusionPipeline"]
+
+
+class AbstractDiffusionPipeline(_Base):
+    def __init__(self, backbone, backbone_kwargs: dict, schedule, timesteps: Union[int, Tensor] = 1000,
+                 cond_fn=None, cond_fn_kwargs: dict = None, optimizer=None, opt_kwargs: Union[Mapping[str, Any], None] = {}):
+        super().__init__()
+        if isinstance(backbone, str):
+            backbone = registry.get("models", backbone)
+        self.backbone = backbone(**backbone_kwargs)
+        self.backbone_kwargs = backbone_kwargs
+        if isinstance(cond_fn, str):
+            cond_fn_class = registry.get("layers", cond_fn)
+            self.backbone.cond_fn = cond_fn_class(**(cond_fn_kwargs or {}))
+        if optimizer is None:
+            optimizer = AdamW          # reference default ("AdamW" string at :72-73 then used as a class)
+        elif isinstance(optimizer, str):
+            optimizer = registry.get("optimizers", optimizer)
+        self.optimizer = optimizer
+        self.schedule = schedule
+        self.metrics = nn.ModuleDict()
+        self.save_hyperparameters({"model_kwargs": backbone_kwargs, "opt_kwargs": dict(opt_kwargs or {})})
+        self.timesteps = timesteps
+        self._python_logger = getLogger(self.__class__.__name__)
+
+    def configure_optimizers(self, mpi_world_size: int = 1):
+        """AdamW defaults merged with the configured kwargs; lr *= sqrt(world) (abstract_diffusion.py:86-148).
+        Unlike the reference the stored kwargs are not mutated."""
+        opt_kwargs = dict(self.hparams.opt_kwargs)
+        spec = getfullargspec(AdamW)
+        names = [a for a in spec.args if a not in ("self", "params")]
+        for key, value in zip(names, spec.defaults or ()):
+            opt_kwargs.setdefault(key, value)
+        opt_kwargs.pop("lr_schedule", None)
+        opt_kwargs["lr"] = opt_kwargs["lr"] * math.sqrt(mpi_world_size)
+        if self.optimizer is AdamW:
+            from ..optim import HipAdamW
+            opt = HipAdamW(self.parameters(), **{k: v for k, v in opt_kwargs.items()
+                                                 if k in ("lr", "betas", "eps", "weight_decay")})
+        else:
+            opt = self.optimizer(self.parameters(), **opt_kwargs)
+        return {"optimizer": opt}
+
+    @property
+    def schedule(self):
+        return self._schedule
+
+    @schedule.setter
+    def schedule(self, _schedule) -> None:
+        self._schedule = _schedule
+
+    def random_timesteps(self, num_steps: int) -> Tensor:
+        """CPU randint with replacement (abstract_diffusion.py:163-169)."""
+        idx = torch.randint(low=0, high=self.timesteps, size=(num_steps,))
+        return torch.arange(0, self.timesteps)[idx]
+
+    def reshape_timesteps(self, data: Tensor, t: Tensor) -> Tensor:
+        return t.view((-1, *((1,) * (data.ndim - 1))))
+
+    def get_schedule_parameters_at_time(self, data: Tensor, t: torch.LongTensor) -> dict:
+        """abstract_diffusion.py:194-220 (kept for API compatibility; the HIP loop reads the
+        device-resident coefficient table instead)."""
+        result = {}
+        for key in ["alpha_t", "beta_t", "alpha_bar_t", "sigma_t"]:
+            result[key] = self.reshape_timesteps(data, self.schedule[key].to(data.device)[t])
+        return result
+
+    def forward_process(self, data: Tensor, t: Union[Tensor, None] = None):
+        ...
+
+    def reverse_process(self, *args, **kwargs):
+        ...
+
+    @staticmethod
+    def make_image_grid(batched_image, filename: str = None):
+        """Image-grid logging (abstract_diffusion.py:240-276) is plotting: out of scope."""
+        return None

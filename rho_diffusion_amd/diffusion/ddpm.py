@@ -1,0 +1,205 @@
+"""DDPM pipeline (reference: rho_diffusion/diffusion/ddpm.py:46-371), same constructor and methods:
+``forward_process`` (q_sample), ``reverse_process`` (ancestral p_sample loop), ``training_step``,
+``p_sample`` / ``generate``, ``save_model_weights``.
+
+The arithmetic runs in the HIP kernels of librho_hip.so:
+  * q_sample       -> rho_q_sample (alpha_bar gathered per batch element on the device)
+  * noise          -> rho_philox_normal (counter-based, reproducible per (seed, offset))
+  * backbone       -> UNet engine (channels-last conv / GroupNorm / attention kernels)
+  * reverse update -> rho_p_sample_step; the step index lives on the device (rho_step_advance), the
+                      loop issues no host synchronisation and no per-step H2D copies
+  * loss           -> rho_mse
+Reference quirks are kept deliberately: 0.8*sqrt(beta) noise scale, z = 0 for t <= 1,
+no update at t = 0 although the backbone is evaluated, clamp to [-1, 1] after every update,
+checkpoint spacing T // 10.
+"""
+from __future__ import annotations
+
+import os
+from typing import Any, Iterable, Mapping, Union
+
+import torch
+from torch import Tensor, nn
+
+from .. import hip
+from ..engine import ops
+from ..registry import registry
+from ..utils import sample_from_discrete_parameter_space, save_model_checkpoint
+from .abstract_diffusion import AbstractDiffusionPipeline
+
+__all__ = ["DDPM"]
+
+
+class DDPM(AbstractDiffusionPipeline):
+    def __init__(self, backbone, backbone_kwargs: dict, schedule, loss_func, timesteps: Union[int, Tensor] = 1000,
+                 cond_fn: str = None, cond_fn_kwargs: dict = None, optimizer=None,
+                 opt_kwargs: Union[Mapping[str, Any], None] = {}, t_checkpoints=None, sampling_batch_size=10,
+                 sample_every_n_epochs=5, sample_parameter_space=None, save_checkpoint_every_n_epochs=10):
+        super().__init__(backbone=backbone, backbone_kwargs=backbone_kwargs, schedule=schedule, timesteps=timesteps,
+                         cond_fn=cond_fn, cond_fn_kwargs=cond_fn_kwargs, optimizer=optimizer, opt_kwargs=opt_kwargs)
+        if isinstance(loss_func, str):
+            loss_func = registry.get("nn", loss_func)
+        if isinstance(loss_func, type):
+            loss_func = loss_func()
+        self.loss_func = loss_func
+        self.t_checkpoints = t_checkpoints
+        self.sampling_batch_size = sampling_batch_size
+        self.sample_every_n_epochs = sample_every_n_epochs
+        self.sample_parameter_space = sample_parameter_space
+        self.save_weights_every_n_epochs = save_checkpoint_every_n_epochs
+        # counter-based RNG state: one stream per rank (seed + rank), offset advances per draw
+        self.noise_seed = int(os.environ.get("RHO_SEED", "777")) + int(os.environ.get("RANK", "0"))
+        self._noise_offset = 0
+        self._nan_flag = None
+        self.nan_check_every = 50
+        self._steps_seen = 0
+
+    # ------------------------------------------------------------------ noise
+    def noise(self, data: Tensor) -> Tensor:
+        """Standard normal with the shape of ``data`` (ddpm.py:101-102), Philox4x32-10 on the device."""
+        hip.require_gpu(data, "data")
+        out = torch.empty(data.shape, dtype=torch.float32, device=data.device)
+        ops.philox_normal(out, self.noise_seed, self._noise_offset)
+        self._noise_offset += (out.numel() + 3) // 4
+        return out
+
+    # ------------------------------------------------------------------ q_sample
+    def forward_process(self, data: Tensor, t: Union[Tensor, None] = None) -> list:
+        """ddpm.py:104-130: returns [x_t, noise]."""
+        hip.require_gpu(data, "data")
+        batch_size = data.size(0)
+        self.schedule.dtype = data.dtype
+        if t is None:
+            t = self.random_timesteps(batch_size)
+        t = t.reshape(-1).to(device=data.device, dtype=torch.int64).contiguous()
+        x0 = data.float().contiguous()
+        noise = self.noise(x0)
+        tables = self.schedule.device_tables(data.device)
+        if self._nan_flag is None or self._nan_flag.device != data.device:
+            self._nan_flag = torch.zeros(1, dtype=torch.int32, device=data.device)
+        x_t = ops.q_sample(x0, noise.contiguous(), t, tables["alpha_bar"], nan_flag=self._nan_flag)
+        return [x_t.type(data.dtype), noise.type(data.dtype)]
+
+    # ------------------------------------------------------------------ p_sample loop
+    @torch.no_grad()  # (reference: inference_mode; no_grad keeps the plan buffers usable in training too)
+    def reverse_process(self, x_T: Tensor, conditions=None, t_checkpoints=None) -> dict:
+        """ddpm.py:132-229.  ``x_T`` is only a shape/device template (:171)."""
+        hip.require_gpu(x_T, "x_T")
+        dev = x_T.device
+        batch_size = x_T.size(0)
+        self.schedule.dtype = x_T.dtype
+        num_checkpoints = len(t_checkpoints) if t_checkpoints is not None else 0
+        buf = None
+        if t_checkpoints is not None:
+            buf = torch.zeros((batch_size, num_checkpoints) + tuple(x_T.shape[1:]), dtype=torch.float32, device=dev)
+
+        denoise_steps = len(self.schedule["alpha_bar_t"])
+        steps_per_ckpt = denoise_steps // 10
+        tables = self.schedule.device_tables(dev)
+
+        x_t = self.noise(x_T).contiguous()
+
+        if conditions is not None:
+            if isinstance(conditions, int):
+                cc = torch.full((batch_size,), fill_value=conditions, device=dev, dtype=torch.long)
+            elif isinstance(conditions, str) and conditions == "auto":
+                cc = torch.randint(0, 10, (batch_size,), device=dev).long()
+            elif isinstance(conditions, torch.Tensor):
+                cc = conditions
+            elif isinstance(conditions, list):
+                cc = torch.tensor(conditions).to(dev)
+        else:
+            cc = None
+
+        engine = self.backbone.engine() if hasattr(self.backbone, "engine") else None
+        t_dev = torch.full((1,), denoise_steps - 1, dtype=torch.int32, device=dev)
+        t_idx = 0
+        for t in range(denoise_steps - 1, -1, -1):
+            z = self.noise(x_t) if t > 1 else None          # drawn before the backbone call (:196-199)
+            if engine is not None:
+                pred = engine.forward(x_t, None, cc, t_scalar_dev=t_dev)
+            else:
+                pred = self.backbone(x_t, torch.full((batch_size,), t, device=dev, dtype=torch.long), cc)
+            if t > 0:
+                ops.p_sample_step(x_t, pred.contiguous(), z, tables["coef"], t_dev)
+            if buf is not None and t % steps_per_ckpt == 0 and t_idx < num_checkpoints:
+                buf[:, t_idx].copy_(x_t)
+                t_idx += 1
+            ops.step_advance(t_dev, None, 0)
+        return {"buffer": buf, "denoised": x_t}
+
+    # ------------------------------------------------------------------ training
+    def _check_nan(self) -> None:
+        """Device-side form of the per-step host check at ddpm.py:268-272: the flag is set by the
+        q_sample kernel and polled every ``nan_check_every`` steps instead of syncing each step."""
+        self._steps_seen += 1
+        if self._nan_flag is not None and self._steps_seen % self.nan_check_every == 0:
+            if int(self._nan_flag.item()) != 0:
+                print("Error: Noised data contains NaNs. Check your noise scheduler.")
+                import sys
+                sys.exit(0)
+
+    def training_step(self, batch: Iterable[Any], batch_idx: int = 0):
+        """ddpm.py:231-288: eps-prediction objective."""
+        if isinstance(batch, list):
+            data, labels = batch
+        elif isinstance(batch, dict):
+            data = batch.get("data")
+            labels = batch.get("label")
+        else:
+            data = batch
+            labels = None
+        self.data_shape = data.shape
+        self.data_dtype = data.dtype
+        batch_size = data.size(0)
+        t = self.random_timesteps(batch_size).to(data.device)
+        x_data, noise = self.forward_process(data, t)
+        self._check_nan()
+        if labels is not None:
+            pred_noise = self.backbone(x_data, t, labels)
+        else:
+            pred_noise = self.backbone(x_data, t)
+        loss = self.loss_func(pred_noise, noise)
+        self.log("train_loss", loss, prog_bar=True)
+        return loss
+
+    def forward(self, batch):
+        return self.backbone(batch)
+
+    def on_train_epoch_end(self) -> None:
+        if (self.current_epoch > 0 and self.sample_every_n_epochs > 0
+                and self.current_epoch % self.sample_every_n_epochs == 0):
+            self.eval()
+            self.generate()
+        if (self.current_epoch > 0 and self.save_weights_every_n_epochs > 0
+                and self.current_epoch % self.save_weights_every_n_epochs == 0):
+            self.eval()
+            self.save_model_weights()
+
+    def p_sample(self, parameter_space, random=False):
+        """ddpm.py:319-355."""
+        if hasattr(self, "data_shape"):
+            shape = [int(x) for x in self.data_shape]
+            shape[0] = self.sampling_batch_size
+        else:
+            shape = [self.sampling_batch_size, self.backbone_kwargs["out_channels"]] + list(self.backbone_kwargs["data_shape"])
+            self.data_dtype = torch.float32
+        sample_data = torch.zeros(shape, dtype=self.data_dtype, device=self.device)
+        cond = None
+        if parameter_space is not None:
+            cond = sample_from_discrete_parameter_space(parameter_space, sample_data.shape[0], random=random, device=self.device)
+        results = self.reverse_process(x_T=sample_data, conditions=cond, t_checkpoints=self.t_checkpoints)
+        self.last_samples = results
+        return self.make_image_grid(results["denoised"], filename="output_%d.png" % self.current_epoch)
+
+    def generate(self, parameter_space=None, random=False):
+        if parameter_space is None:
+            parameter_space = self.sample_parameter_space
+        return self.p_sample(parameter_space=parameter_space, random=random)
+
+    def save_model_weights(self):
+        print("saving model checkpoints...")
+        save_model_checkpoint(self.backbone, "model.pth")
+
+    def validation_step(self, batch, batch_idx: int = 0):
+        return 0

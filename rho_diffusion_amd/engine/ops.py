@@ -1,0 +1,236 @@
+"""Tensor-level wrappers over the C ABI (include/rho_hip.h): shape/dtype checks on the host,
+raw device pointers into the kernels.  All functions enqueue on the current torch stream and
+return torch tensors that own the device memory.  No arithmetic happens in PyTorch here."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from .. import hip
+from ..hip import ConvDesc, RhoHipError, check, dtype_code, ptr, stream
+
+Tensor = torch.Tensor
+
+
+def _f32c(t: Tensor, name: str) -> Tensor:
+    hip.require_gpu(t, name)
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise RhoHipError(f"{name} must be contiguous float32, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t
+
+
+def spatial5(shape: Sequence[int]) -> Tuple[int, int, int]:
+    """(D, H, W) of a 1/2/3-D spatial shape (missing leading axes are 1)."""
+    s = list(shape)
+    while len(s) < 3:
+        s.insert(0, 1)
+    return int(s[0]), int(s[1]), int(s[2])
+
+
+def elem_chunk(dtype: torch.dtype) -> int:
+    """channels per 64-byte chunk: the conv kernel's channel granularity."""
+    return 32 if dtype == torch.bfloat16 else 16
+
+
+# ----------------------------------------------------------------------------- diffusion loops
+def q_sample(x0: Tensor, eps: Tensor, t: Tensor, alpha_bar: Tensor, out: Optional[Tensor] = None,
+             nan_flag: Optional[Tensor] = None) -> Tensor:
+    x0, eps, alpha_bar = _f32c(x0, "x0"), _f32c(eps, "eps"), _f32c(alpha_bar, "alpha_bar")
+    if t.dtype != torch.int64 or not t.is_cuda:
+        raise RhoHipError("t must be an int64 GPU tensor")
+    out = torch.empty_like(x0) if out is None else out
+    B = x0.shape[0]
+    check(hip.lib().rho_q_sample(ptr(x0), ptr(eps), ptr(out), ptr(alpha_bar), ptr(t), B, x0.numel() // B,
+                                 ptr(nan_flag), stream()), "rho_q_sample")
+    return out
+
+
+def p_sample_step(x: Tensor, eps_hat: Tensor, z: Optional[Tensor], coef_table: Tensor, t_dev: Tensor) -> Tensor:
+    _f32c(x, "x"), _f32c(eps_hat, "eps_hat"), _f32c(coef_table, "coef_table")
+    if t_dev.dtype != torch.int32:
+        raise RhoHipError("t_dev must be int32[1] on the GPU")
+    check(hip.lib().rho_p_sample_step(ptr(x), ptr(eps_hat), ptr(z), ptr(coef_table), ptr(t_dev), x.numel(), stream()),
+          "rho_p_sample_step")
+    return x
+
+
+def step_advance(t_dev: Optional[Tensor], offset_dev: Optional[Tensor], delta: int) -> None:
+    check(hip.lib().rho_step_advance(ptr(t_dev), ptr(offset_dev), delta, stream()), "rho_step_advance")
+
+
+def philox_normal(out: Tensor, seed: int, offset: int = 0, offset_dev: Optional[Tensor] = None) -> Tensor:
+    _f32c(out, "out")
+    check(hip.lib().rho_philox_normal(ptr(out), out.numel(), seed & (2 ** 64 - 1), offset, ptr(offset_dev), stream()),
+          "rho_philox_normal")
+    return out
+
+
+def mse(a: Tensor, b: Tensor, want_grad: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+    _f32c(a, "a"), _f32c(b, "b")
+    loss = torch.empty(1, dtype=torch.float32, device=a.device)
+    grad = torch.empty_like(a) if want_grad else None
+    check(hip.lib().rho_mse(ptr(a), ptr(b), ptr(loss), ptr(grad), a.numel(), stream()), "rho_mse")
+    return loss, grad
+
+
+def adamw(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, beta1: float, beta2: float, eps: float,
+          weight_decay: float, step: int) -> None:
+    for name, t in (("p", p), ("g", g), ("m", m), ("v", v)):
+        _f32c(t, name)
+    check(hip.lib().rho_adamw(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step, stream()),
+          "rho_adamw")
+
+
+# ----------------------------------------------------------------------------- embeddings
+def embed_gather(table: Tensor, t: Optional[Tensor], batch: int, t_scalar_dev: Optional[Tensor] = None,
+                 out: Optional[Tensor] = None) -> Tensor:
+    _f32c(table, "table")
+    rows, dim = table.shape
+    out = torch.empty(batch, dim, dtype=torch.float32, device=table.device) if out is None else out
+    if t is not None and (t.dtype != torch.int64 or not t.is_cuda or not t.is_contiguous()):
+        raise RhoHipError("t must be a contiguous int64 GPU tensor")
+    check(hip.lib().rho_embed_gather(ptr(table), ptr(t), ptr(t_scalar_dev), ptr(out), batch, dim, rows, stream()),
+          "rho_embed_gather")
+    return out
+
+
+def linear(x: Tensor, w: Tensor, bias: Optional[Tensor], add: Optional[Tensor] = None, act_in: bool = False,
+           act_out: bool = False, out: Optional[Tensor] = None) -> Tensor:
+    _f32c(x, "x"), _f32c(w, "w")
+    B, K = x.shape
+    O = w.shape[0]
+    if w.shape[1] != K:
+        raise RhoHipError(f"linear: weight {tuple(w.shape)} does not match input {tuple(x.shape)}")
+    out = torch.empty(B, O, dtype=torch.float32, device=x.device) if out is None else out
+    check(hip.lib().rho_linear(ptr(x), ptr(w), ptr(bias), ptr(add), ptr(out), B, K, O, int(act_in), int(act_out), stream()),
+          "rho_linear")
+    return out
+
+
+# ----------------------------------------------------------------------------- layout
+def pack_input(x: Tensor, dtype: torch.dtype, cpad: Optional[int] = None, out: Optional[Tensor] = None) -> Tensor:
+    """[N, C, *S] float32 -> channels-last [N, D, H, W, Cpad] in the engine dtype."""
+    _f32c(x, "x")
+    N, Cc = x.shape[0], x.shape[1]
+    D, H, W = spatial5(x.shape[2:])
+    ck = elem_chunk(dtype)
+    cpad = cpad or ((Cc + ck - 1) // ck) * ck
+    out = torch.empty(N, D, H, W, cpad, dtype=dtype, device=x.device) if out is None else out
+    check(hip.lib().rho_pack_input(ptr(x), ptr(out), dtype_code(dtype), N, Cc, D * H * W, cpad, stream()), "rho_pack_input")
+    return out
+
+
+def prep_conv_weight(w: Tensor, dtype: torch.dtype, coutp: Optional[int] = None, cinp: Optional[int] = None,
+                     row_src: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """PyTorch conv weight [Cout, Cin, *k] float32 -> [taps, CoutP, CinP] in the engine dtype."""
+    _f32c(w, "w")
+    cout, cin = w.shape[0], w.shape[1]
+    taps = int(math.prod(w.shape[2:])) if w.dim() > 2 else 1
+    ck = elem_chunk(dtype)
+    cinp = cinp or ((cin + ck - 1) // ck) * ck
+    coutp = coutp or ((cout + 31) // 32) * 32
+    out = torch.empty(taps, coutp, cinp, dtype=dtype, device=w.device) if out is None else out
+    if row_src is not None and (row_src.dtype != torch.int32 or row_src.numel() != coutp):
+        raise RhoHipError("row_src must be int32[coutp]")
+    check(hip.lib().rho_prep_conv_weight(ptr(w), ptr(out), dtype_code(dtype), cout, cin, taps, coutp, cinp, ptr(row_src), stream()),
+          "rho_prep_conv_weight")
+    return out
+
+
+# ----------------------------------------------------------------------------- GroupNorm
+def gn_nblk(s: int) -> int:
+    return int(hip.lib().rho_gn_nblk(s))
+
+
+def gn_coeffs(x1: Tensor, x2: Optional[Tensor], gamma: Tensor, beta: Tensor, scale: Optional[Tensor] = None,
+              shift: Optional[Tensor] = None, film_stride: int = 0, partials: Optional[Tensor] = None,
+              a: Optional[Tensor] = None, b: Optional[Tensor] = None, stats: Optional[Tensor] = None):
+    """GroupNorm(32) statistics of the (virtually concatenated) channels-last input and the folded
+    per-(sample, channel) affine (a, b) consumed by the conv prologue."""
+    N = x1.shape[0]
+    c1 = x1.shape[-1]
+    c2 = x2.shape[-1] if x2 is not None else 0
+    S = x1.numel() // (N * c1)
+    Cc = c1 + c2
+    nblk = gn_nblk(S)
+    dev = x1.device
+    partials = torch.empty(N * nblk * (Cc // 8) * 16, dtype=torch.float32, device=dev) if partials is None else partials
+    a = torch.empty(N, Cc, dtype=torch.float32, device=dev) if a is None else a
+    b = torch.empty(N, Cc, dtype=torch.float32, device=dev) if b is None else b
+    stats = torch.empty(N, 32, 2, dtype=torch.float32, device=dev) if stats is None else stats
+    L = hip.lib()
+    check(L.rho_gn_partial(ptr(x1), c1, ptr(x2), c2, dtype_code(x1.dtype), N, S, ptr(partials), stream()), "rho_gn_partial")
+    check(L.rho_gn_finalize(ptr(partials), N, Cc, S, nblk, ptr(gamma), ptr(beta), ptr(scale), ptr(shift), film_stride,
+                            ptr(stats), ptr(a), ptr(b), stream()), "rho_gn_finalize")
+    return a, b, stats
+
+
+# ----------------------------------------------------------------------------- convolution
+def make_conv_desc(x1: Tensor, x2: Optional[Tensor], w: Tensor, bias: Tensor, *, kernel: Tuple[int, int, int],
+                   cout: int, split: int, y: Optional[Tensor], y2: Optional[Tensor], stride_hw=(1, 1), up_hw=(0, 0),
+                   pre_a: Optional[Tensor] = None, pre_b: Optional[Tensor] = None, pre_silu: bool = False,
+                   res: Optional[Tensor] = None, res_add: Optional[Tensor] = None, res_add_stride: int = 0) -> ConvDesc:
+    N, D, H, W, c1 = x1.shape
+    d = ConvDesc()
+    d.x1, d.x2 = ptr(x1), ptr(x2)
+    d.pre_a, d.pre_b = ptr(pre_a), ptr(pre_b)
+    d.w, d.bias = ptr(w), ptr(bias)
+    d.res, d.res_add = ptr(res), ptr(res_add)
+    d.y, d.y2 = ptr(y), ptr(y2)
+    d.dtype = dtype_code(x1.dtype)
+    d.y2_f32 = int(y2 is not None and y2.dtype == torch.float32)
+    d.c1 = c1
+    d.c2 = x2.shape[-1] if x2 is not None else 0
+    d.cout, d.coutp, d.split = cout, w.shape[1], split
+    d.n, d.d, d.h, d.w_ = N, D, H, W
+    d.kd, d.kh, d.kw = kernel
+    d.sh, d.sw = stride_hw
+    d.up_h, d.up_w = up_hw
+    d.pre_silu = int(pre_silu)
+    d.res_add_stride = res_add_stride
+    if w.shape[2] != d.c1 + d.c2:
+        raise RhoHipError(f"conv: prepared weight has {w.shape[2]} input channels, inputs provide {d.c1 + d.c2}")
+    return d
+
+
+def conv_out_shape(x_shape, kernel, stride_hw, up_hw):
+    N, D, H, W, _ = x_shape
+    kd, kh, kw = kernel
+    ho = H * 2 if up_hw[0] else (H + 2 * (kh // 2) - kh) // stride_hw[0] + 1
+    wo = W * 2 if up_hw[1] else (W + 2 * (kw // 2) - kw) // stride_hw[1] + 1
+    return N, D, ho, wo
+
+
+def conv_launch(desc: ConvDesc) -> None:
+    check(hip.lib().rho_conv_nd_fwd(C.byref(desc), stream()), "rho_conv_nd_fwd")
+
+
+def conv(x1: Tensor, x2: Optional[Tensor], w: Tensor, bias: Tensor, *, kernel, cout: int, split: Optional[int] = None,
+         stride_hw=(1, 1), up_hw=(0, 0), pre_a=None, pre_b=None, pre_silu=False, res=None, res_add=None,
+         res_add_stride: int = 0, y2_dtype: Optional[torch.dtype] = None):
+    """Allocate outputs and run one convolution. Returns (y channels-last or None, y2 channel-major or None)."""
+    split = cout if split is None else split
+    N, Do, Ho, Wo = conv_out_shape(x1.shape, kernel, stride_hw, up_hw)
+    y = torch.empty(N, Do, Ho, Wo, split, dtype=x1.dtype, device=x1.device) if split > 0 else None
+    y2 = None
+    if split < cout:
+        y2 = torch.empty(N, cout - split, Do * Ho * Wo, dtype=y2_dtype or x1.dtype, device=x1.device)
+    d = make_conv_desc(x1, x2, w, bias, kernel=kernel, cout=cout, split=split, y=y, y2=y2, stride_hw=stride_hw, up_hw=up_hw,
+                       pre_a=pre_a, pre_b=pre_b, pre_silu=pre_silu, res=res, res_add=res_add, res_add_stride=res_add_stride)
+    conv_launch(d)
+    return y, y2
+
+
+# ----------------------------------------------------------------------------- attention
+def attention(qk: Tensor, vt: Tensor, heads: int, out: Optional[Tensor] = None) -> Tensor:
+    """qk channels-last [B, T, 2C], vt channel-major [B, C, T] -> channels-last [B, T, C]."""
+    B, T, C2 = qk.shape
+    Cc = C2 // 2
+    ch = Cc // heads
+    out = torch.empty(B, T, Cc, dtype=qk.dtype, device=qk.device) if out is None else out
+    check(hip.lib().rho_attention_fwd(ptr(qk), ptr(vt), ptr(out), dtype_code(qk.dtype), B, T, heads, ch, stream()),
+          "rho_attention_fwd")
+    return out

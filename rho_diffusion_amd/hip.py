@@ -1,0 +1,114 @@
+"""ctypes binding of librho_hip.so (C ABI: include/rho_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails, the product path
+raises.  PyTorch is used only for device memory, streams and torch.distributed.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librho_hip.so")
+
+RHO_F32 = 0
+RHO_BF16 = 1
+
+c_void_p, c_int, c_int32, c_int64, c_uint64, c_float = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_uint64, C.c_float
+
+
+class ConvDesc(C.Structure):
+    """struct rho_conv_desc (include/rho_hip.h)."""
+    _fields_ = [
+        ("x1", c_void_p), ("x2", c_void_p), ("pre_a", c_void_p), ("pre_b", c_void_p), ("w", c_void_p),
+        ("bias", c_void_p), ("res", c_void_p), ("res_add", c_void_p), ("y", c_void_p), ("y2", c_void_p),
+        ("dtype", c_int32), ("y2_f32", c_int32), ("c1", c_int32), ("c2", c_int32),
+        ("cout", c_int32), ("coutp", c_int32), ("split", c_int32),
+        ("n", c_int32), ("d", c_int32), ("h", c_int32), ("w_", c_int32),
+        ("kd", c_int32), ("kh", c_int32), ("kw", c_int32), ("sh", c_int32), ("sw", c_int32),
+        ("up_h", c_int32), ("up_w", c_int32), ("pre_silu", c_int32), ("res_add_stride", c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/rho_hip.h declares
+SIGNATURES = {
+    "rho_abi_version": (c_int, []),
+    "rho_build_info": (C.c_char_p, []),
+    "rho_q_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "rho_p_sample_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "rho_step_advance": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p]),
+    "rho_philox_normal": (c_int, [c_void_p, c_int64, c_uint64, c_uint64, c_void_p, c_void_p]),
+    "rho_mse": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "rho_adamw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int32, c_void_p]),
+    "rho_embed_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "rho_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "rho_pack_input": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p]),
+    "rho_prep_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    "rho_gn_nblk": (c_int, [c_int64]),
+    "rho_gn_partial": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p]),
+    "rho_gn_finalize": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rho_conv_nd_fwd": (c_int, [C.POINTER(ConvDesc), c_void_p]),
+    "rho_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p]),
+}
+
+
+class RhoHipError(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load(path: str = LIB_PATH) -> C.CDLL:
+    """dlopen the library and bind every declared symbol (works without a GPU)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RhoHipError(
+            f"{path} not found: build it with `python -m rho_diffusion_amd.build` (hipcc --offload-arch=gfx950). "
+            "There is no CPU/PyTorch fallback for the product path.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError => ABI mismatch, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def lib() -> C.CDLL:
+    return load()
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        kind = {-1: "RHO_E_ARG", -2: "RHO_E_ALIGN", -3: "RHO_E_SHAPE"}.get(rc, f"hipError {rc}")
+        raise RhoHipError(f"{what} failed: {kind}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(t: torch.Tensor, name: str = "tensor") -> None:
+    if not t.is_cuda:
+        raise RhoHipError(f"{name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return RHO_F32
+    if dt == torch.bfloat16:
+        return RHO_BF16
+    raise RhoHipError(f"unsupported engine dtype {dt}")

@@ -1,0 +1,59 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol include/rho_hip.h declares,
+and the ctypes binding declares the same set (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "rho_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rho_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_surface():
+    names = _declared()
+    for must in ["rho_q_sample", "rho_p_sample_step", "rho_philox_normal", "rho_conv_nd_fwd", "rho_attention_fwd",
+                 "rho_gn_partial", "rho_gn_finalize", "rho_adamw", "rho_mse", "rho_linear", "rho_embed_gather"]:
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from rho_diffusion_amd import hip
+    if not os.path.exists(hip.LIB_PATH):
+        from rho_diffusion_amd.build import build
+        build(verbose=False)
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    for name in _declared():
+        assert hasattr(lib, name), f"{name} declared in rho_hip.h but not exported"
+
+
+def test_ctypes_binding_matches_header():
+    from rho_diffusion_amd import hip
+    assert sorted(hip.SIGNATURES.keys()) == _declared()
+    lib = hip.load()
+    assert lib.rho_abi_version() >= 1
+    assert b"gfx950" in lib.rho_build_info()
+
+
+def test_conv_desc_struct_layout():
+    """ctypes struct must mirror `struct rho_conv_desc` field for field."""
+    from rho_diffusion_amd.hip import ConvDesc
+    text = open(os.path.join(ROOT, "include", "rho_hip.h")).read()
+    body = text[text.index("typedef struct rho_conv_desc {"):text.index("} rho_conv_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.split(",")
+        first = names[0].split()[-1].lstrip("*")
+        fields.append(first)
+        fields.extend(n.strip().lstrip("*") for n in names[1:])
+    assert [f[0] for f in ConvDesc._fields_] == fields
+    assert ctypes.sizeof(ConvDesc) == 10 * 8 + 20 * 4

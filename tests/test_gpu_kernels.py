@@ -1,0 +1,310 @@
+"""-m gpu: every HIP kernel of librho_hip.so against the CPU oracle (oracle/ref_torch.py) on the
+same seeded inputs.  Tolerances: fp32 kernels rel-L2 <= 2e-5 (summation order only);
+bf16 kernels rel-L2 <= 6e-3 against the oracle evaluated on bf16-rounded operands (fp32
+accumulate, one output rounding = 2^-9 relative)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import det_normal, det_uniform, load_golden, rel_l2
+from gpu_util import DEV, bf16_round, from_cl, rnd, to_cl, tol
+from oracle import ref_torch as R
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from rho_diffusion_amd.engine import ops as o
+    from rho_diffusion_amd import hip
+    hip.load()
+    return o
+
+
+# ----------------------------------------------------------------------------- diffusion loops
+@pytest.mark.parametrize("shape", [(4, 1, 8, 8, 8), (3, 3, 5, 7), (2, 1, 33)])
+def test_q_sample(ops, shape):
+    sched = R.linear_schedule(1000, 1e-3, 0.02)
+    x0 = det_uniform(shape, "qx0", 0, 1)
+    eps = det_normal(shape, "qeps")
+    t = torch.tensor([(331 * i + 7) % 1000 for i in range(shape[0])])
+    ref = R.q_sample(x0, t, eps, sched["alpha_bar_t"])
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    out = ops.q_sample(x0.to(DEV), eps.to(DEV), t.to(DEV), sched["alpha_bar_t"].to(DEV), nan_flag=flag)
+    assert rel_l2(out, ref) < 1e-6
+    assert int(flag.item()) == 0
+    bad = x0.clone()
+    bad.view(-1)[5] = float("nan")
+    ops.q_sample(bad.to(DEV), eps.to(DEV), t.to(DEV), sched["alpha_bar_t"].to(DEV), nan_flag=flag)
+    assert int(flag.item()) == 1
+
+
+@pytest.mark.parametrize("t", [999, 500, 2, 1, 0])
+def test_p_sample_step(ops, t):
+    from rho_diffusion_amd.diffusion.schedule import LinearSchedule
+    s = LinearSchedule(1000, 1e-3, 0.02)
+    sched = R.linear_schedule(1000, 1e-3, 0.02)
+    shape = (2, 1, 6, 10, 10)
+    x = det_normal(shape, "px") * 0.7
+    eh = det_normal(shape, "pe")
+    z = det_normal(shape, "pz")
+    xg = x.to(DEV).clone()
+    t_dev = torch.tensor([t], dtype=torch.int32, device=DEV)
+    ops.p_sample_step(xg, eh.to(DEV), z.to(DEV), s.device_tables(DEV)["coef"], t_dev)
+    if t == 0:
+        ref = x                                             # no update at t = 0 (ddpm.py:210)
+    else:
+        ref = R.p_sample_step(x, eh, t, sched, z if t > 1 else torch.zeros_like(z))
+    assert rel_l2(xg, ref) < 2e-6
+
+
+def test_step_advance(ops):
+    t_dev = torch.tensor([5], dtype=torch.int32, device=DEV)
+    off = torch.tensor([10], dtype=torch.int64, device=DEV)
+    ops.step_advance(t_dev, off, 7)
+    assert int(t_dev.item()) == 4 and int(off.item()) == 17
+
+
+def test_philox_normal(ops):
+    n = 1 << 20
+    a = torch.empty(n, device=DEV)
+    b = torch.empty(n, device=DEV)
+    ops.philox_normal(a, 777, 0)
+    ops.philox_normal(b, 777, 0)
+    assert torch.equal(a, b)                                # reproducible
+    # offset continuity: the stream does not depend on how it is cut into launches
+    c = torch.empty(n // 2, device=DEV)
+    ops.philox_normal(c, 777, n // 8)
+    assert torch.equal(c, a[n // 2:])
+    ops.philox_normal(b, 778, 0)
+    assert not torch.equal(a, b)
+    a = a.double().cpu()
+    assert abs(a.mean()) < 5e-3 and abs(a.std() - 1) < 5e-3
+    assert abs((a ** 3).mean()) < 2e-2 and abs((a ** 4).mean() - 3) < 5e-2
+    assert torch.isfinite(a).all()
+    od = torch.tensor([n // 8], dtype=torch.int64, device=DEV)
+    ops.philox_normal(c, 777, 0, offset_dev=od)
+    assert torch.equal(c.cpu().double(), a[n // 2:])
+
+
+def test_mse(ops):
+    a = det_normal((3, 1, 9, 11), "ma")
+    b = det_normal((3, 1, 9, 11), "mb")
+    loss, grad = ops.mse(a.to(DEV), b.to(DEV), want_grad=True)
+    assert abs(loss.item() - F.mse_loss(a, b).item()) < 1e-6
+    assert rel_l2(grad, 2 * (a - b) / a.numel()) < 1e-6
+
+
+def test_adamw_matches_golden(ops):
+    g = load_golden("g8_adamw.npz")
+    p = det_normal((257,), "adam_p").to(DEV)
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    for step in range(1, 4):
+        ops.adamw(p, det_normal((257,), f"adam_g{step}").to(DEV), m, v, 1e-4, 0.9, 0.999, 1e-8, 1e-2, step)
+        assert rel_l2(p, torch.from_numpy(g[f"p{step}"])) < 1e-6
+
+
+def test_embed_and_linear(ops):
+    tab = R.sinusoidal_embedding(torch.arange(1000), 64)
+    t = torch.tensor([0, 1, 17, 500, 999])
+    out = ops.embed_gather(tab.to(DEV), t.to(DEV), 5)
+    assert torch.equal(out.cpu(), tab[t])
+    ts = torch.tensor([17], dtype=torch.int32, device=DEV)
+    out = ops.embed_gather(tab.to(DEV), None, 3, t_scalar_dev=ts)
+    assert torch.equal(out.cpu(), tab[17].expand(3, -1))
+    for (B, K, O, ai, ao) in [(5, 64, 256, False, True), (5, 256, 1000, True, False), (3, 1024, 130, False, False)]:
+        x = det_normal((B, K), "lx")
+        w = det_normal((O, K), "lw") / math.sqrt(K)
+        b = det_normal((O,), "lb")
+        add = det_normal((B, O), "la")
+        ref = F.linear(F.silu(x) if ai else x, w, b) + add
+        ref = F.silu(ref) if ao else ref
+        out = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), add.to(DEV), act_in=ai, act_out=ao)
+        assert rel_l2(out, ref) < 2e-6
+
+
+# ----------------------------------------------------------------------------- GroupNorm coefficients
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c1,c2,spatial", [(64, 0, (3, 5, 7)), (32, 64, (4, 6, 6)), (128, 0, (40, 40)), (256, 128, (9,)),
+                                           (512, 512, (2, 4, 4))])
+def test_gn_coeffs(ops, dtype, c1, c2, spatial):
+    N = 3
+    x1 = rnd(det_normal((N, c1, *spatial), "g1") * 2 + 0.7, dtype)
+    x2 = rnd(det_normal((N, c2, *spatial), "g2") * 0.5 - 1.0, dtype) if c2 else None
+    C = c1 + c2
+    gamma = 1 + 0.2 * det_uniform((C,), "gg")
+    beta = 0.1 * det_uniform((C,), "gb")
+    film = det_normal((N, 2 * C), "gf") * 0.3
+    xcat = torch.cat([x1, x2], 1) if c2 else x1
+    a, b, st = ops.gn_coeffs(to_cl(x1, dtype), to_cl(x2, dtype) if c2 else None, gamma.to(DEV), beta.to(DEV),
+                             scale=film.to(DEV), shift=film.to(DEV)[:, C:], film_stride=2 * C)
+    # oracle: y = GN(x) * (1 + scale) + shift  ==  a * x + b
+    ref = R.group_norm32(xcat, gamma, beta)
+    shape = (N, C) + (1,) * len(spatial)
+    ref = ref * (1 + film[:, :C].reshape(shape)) + film[:, C:].reshape(shape)
+    got = a.cpu().reshape(shape) * xcat + b.cpu().reshape(shape)
+    assert rel_l2(got, ref) < 1e-5
+    a0, b0, _ = ops.gn_coeffs(to_cl(x1, dtype), to_cl(x2, dtype) if c2 else None, gamma.to(DEV), beta.to(DEV))
+    got = a0.cpu().reshape(shape) * xcat + b0.cpu().reshape(shape)
+    assert rel_l2(got, R.group_norm32(xcat, gamma, beta)) < 1e-5
+
+
+# ----------------------------------------------------------------------------- convolution
+def _oracle_conv(dims, x, w, b, stride, up, pre, pre_silu, dtype):
+    xx = x
+    if pre is not None:
+        a, bb = pre
+        shape = a.shape + (1,) * dims
+        xx = a.reshape(shape) * xx + bb.reshape(shape)
+        if pre_silu:
+            xx = F.silu(xx)
+        xx = rnd(xx, dtype)          # the loader rounds the activated tile to the MFMA input type
+    if up:
+        xx = R.upsample(dims, xx)
+    return R.conv_nd(dims, xx, w, b, stride=stride, padding=w.shape[-1] // 2)
+
+
+CONV_CASES = [
+    # name, dims, N, cin1, cin2, cout, spatial, k, stride, up, prologue, residual
+    ("3d_basic", 3, 2, 32, 0, 64, (4, 8, 8), 3, 1, False, False, False),
+    ("3d_ragged", 3, 1, 64, 0, 32, (5, 6, 7), 3, 1, False, True, True),
+    ("3d_concat", 3, 2, 64, 32, 64, (4, 8, 8), 3, 1, False, True, True),
+    ("3d_wide", 3, 1, 128, 128, 128, (4, 4, 8), 3, 1, False, True, False),
+    ("3d_down", 3, 2, 32, 0, 32, (4, 8, 8), 3, (1, 2, 2), False, False, False),
+    ("3d_down_odd", 3, 1, 32, 0, 64, (3, 7, 9), 3, (1, 2, 2), False, False, False),
+    ("3d_up", 3, 2, 32, 0, 32, (4, 4, 4), 3, 1, True, False, False),
+    ("3d_1x1", 3, 2, 96, 0, 64, (3, 5, 7), 1, 1, False, False, False),
+    ("2d_basic", 2, 3, 32, 0, 64, (12, 10), 3, 1, False, True, True),
+    ("2d_concat", 2, 2, 128, 64, 128, (16, 16), 3, 1, False, True, False),
+    ("2d_down", 2, 2, 64, 0, 64, (16, 12), 3, 2, False, False, False),
+    ("2d_up", 2, 2, 64, 0, 64, (6, 8), 3, 1, True, False, False),
+    ("2d_1x1_concat", 2, 2, 64, 32, 32, (8, 8), 1, 1, False, False, False),
+    ("1d_basic", 1, 2, 32, 0, 32, (40,), 3, 1, False, True, True),
+    ("1d_down", 1, 2, 32, 0, 32, (32,), 3, 2, False, False, False),
+    ("1d_up", 1, 2, 32, 0, 32, (16,), 3, 1, True, False, False),
+    ("1d_1x1", 1, 2, 64, 0, 192, (16,), 1, 1, False, True, True),
+    ("3d_big_tile", 3, 1, 64, 0, 64, (8, 16, 16), 3, 1, False, True, True),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv(ops, dtype, case):
+    name, dims, N, c1, c2, cout, spatial, k, stride, up, prologue, residual = case
+    cin = c1 + c2
+    x1 = rnd(det_normal((N, c1, *spatial), name + "x1"), dtype)
+    x2 = rnd(det_normal((N, c2, *spatial), name + "x2"), dtype) if c2 else None
+    w = rnd(det_normal((cout, cin) + (k,) * dims, name + "w") / math.sqrt(cin * k ** dims), dtype)
+    b = det_normal((cout,), name + "b") * 0.1
+    pre = None
+    if prologue:
+        pre = (1 + 0.3 * det_normal((N, cin), name + "a"), 0.2 * det_normal((N, cin), name + "pb"))
+    xcat = torch.cat([x1, x2], 1) if c2 else x1
+    ref = _oracle_conv(dims, xcat, w, b, stride, up, pre, True, dtype)
+    res = rnd(det_normal(tuple(ref.shape), name + "r"), dtype) if residual else None
+    if residual:
+        ref = ref + res
+    sdims = stride if isinstance(stride, tuple) else (stride,) * dims
+    s3 = (1,) * (3 - dims) + tuple(sdims)
+    stride_hw = (s3[1], s3[2])
+    up_hw = ((1, 1) if dims >= 2 else (0, 1)) if up else (0, 0)
+    kernel = (1,) * (3 - dims) + (k,) * dims
+    wp = ops.prep_conv_weight(w.to(DEV), dtype)
+    bp = b.to(DEV)
+    y, _ = ops.conv(to_cl(x1, dtype), to_cl(x2, dtype) if c2 else None, wp, bp, kernel=kernel, cout=cout,
+                    stride_hw=stride_hw, up_hw=up_hw, pre_a=pre[0].to(DEV) if pre else None,
+                    pre_b=pre[1].to(DEV) if pre else None, pre_silu=True, res=to_cl(res, dtype) if residual else None)
+    got = from_cl(y, dims)
+    assert got.shape == ref.shape
+    assert rel_l2(got, ref) < tol(dtype), name
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_split_and_small_cout(ops, dtype):
+    """channel-major second output (attention V^T / final NC* float32 head) and res_add."""
+    dims, N, cin, spatial = 2, 2, 64, (8, 8)
+    x = rnd(det_normal((N, cin, *spatial), "sx"), dtype)
+    # (a) qkv-like: 3C outputs, first 2C channels-last, last C channel-major
+    C = 64
+    w = rnd(det_normal((3 * C, cin, 1, 1), "sw") / 8, dtype)
+    b = det_normal((3 * C,), "sb") * 0.1
+    ref = F.conv2d(x, w, b)
+    y, y2 = ops.conv(to_cl(x, dtype), None, ops.prep_conv_weight(w.to(DEV), dtype), b.to(DEV), kernel=(1, 1, 1),
+                     cout=3 * C, split=2 * C)
+    assert rel_l2(from_cl(y, dims), ref[:, :2 * C]) < tol(dtype)
+    assert rel_l2(y2.float().cpu().reshape(N, C, *spatial), ref[:, 2 * C:]) < tol(dtype)
+    # (b) head-like: 3 output channels, float32 NC* output, + additive per-(n, co) embedding on a 32-ch conv
+    w = rnd(det_normal((3, cin, 3, 3), "hw") / 24, dtype)
+    b = det_normal((3,), "hb")
+    ref = F.conv2d(x, w, b, padding=1)
+    wp = ops.prep_conv_weight(w.to(DEV), dtype)
+    bp = torch.zeros(wp.shape[1], device=DEV)
+    bp[:3] = b.to(DEV)
+    _, y2 = ops.conv(to_cl(x, dtype), None, wp, bp, kernel=(1, 3, 3), cout=3, split=0, y2_dtype=torch.float32)
+    assert y2.dtype == torch.float32
+    assert rel_l2(y2.cpu().reshape(N, 3, *spatial), ref) < tol(dtype, bf16=2e-3)
+    w = rnd(det_normal((32, cin, 3, 3), "aw") / 24, dtype)
+    b = det_normal((32,), "ab")
+    emb = det_normal((N, 40), "ae")
+    ref = F.conv2d(x, w, b, padding=1) + emb[:, 4:36].reshape(N, 32, 1, 1)
+    y, _ = ops.conv(to_cl(x, dtype), None, ops.prep_conv_weight(w.to(DEV), dtype), b.to(DEV), kernel=(1, 3, 3), cout=32,
+                    res_add=emb.to(DEV)[:, 4:], res_add_stride=40)
+    assert rel_l2(from_cl(y, dims), ref) < tol(dtype)
+
+
+def test_prep_conv_weight_layout(ops):
+    w = det_normal((5, 3, 3, 3, 3), "pw")
+    out = ops.prep_conv_weight(w.to(DEV), torch.float32)            # [27, 32, 16]
+    assert tuple(out.shape) == (27, 32, 16)
+    ref = torch.zeros(27, 32, 16)
+    ref[:, :5, :3] = w.reshape(5, 3, 27).permute(2, 0, 1)
+    assert torch.equal(out.cpu(), ref)
+    src = torch.tensor([4, 3, 2, 1, 0] + [-1] * 27, dtype=torch.int32, device=DEV)
+    out = ops.prep_conv_weight(w.to(DEV), torch.bfloat16, row_src=src)
+    assert torch.equal(out.float().cpu()[:, :5, :3], bf16_round(ref[:, [4, 3, 2, 1, 0], :3]))
+
+
+def test_pack_input(ops):
+    x = det_normal((2, 3, 4, 5, 6), "pk")
+    for dt in DTYPES:
+        y = ops.pack_input(x.to(DEV), dt)
+        assert y.shape[-1] == (32 if dt == torch.bfloat16 else 16)
+        assert torch.equal(from_cl(y[..., :3], 3), rnd(x, dt))
+        assert float(y[..., 3:].float().abs().max()) == 0.0
+
+
+# ----------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,T,heads,ch", [(2, 64, 4, 16), (2, 256, 2, 32), (1, 100, 1, 32), (2, 4, 1, 256), (1, 300, 4, 64),
+                                          (1, 192, 2, 128), (1, 16, 4, 64)])
+def test_attention(ops, dtype, B, T, heads, ch):
+    C = heads * ch
+    q = rnd(det_normal((B, C, T), f"aq{T}{ch}"), dtype)
+    k = rnd(det_normal((B, C, T), f"ak{T}{ch}"), dtype)
+    v = rnd(det_normal((B, C, T), f"av{T}{ch}"), dtype)
+    ref = R.qkv_attention(torch.cat([q, k, v], 1), heads, new_order=True)          # canonical [Q|K|V] order
+    qk = torch.cat([q, k], 1).permute(0, 2, 1).contiguous().to(DEV).to(dtype)      # [B, T, 2C]
+    vt = v.contiguous().to(DEV).to(dtype)                                          # [B, C, T]
+    out = ops.attention(qk, vt, heads)                                             # [B, T, C]
+    got = out.float().cpu().permute(0, 2, 1)
+    assert rel_l2(got, ref) < tol(dtype, f32=1e-5, bf16=1e-2)
+
+
+def test_attention_online_softmax_rescale(ops):
+    """Force the running-max rescale branch: one key far above the rest, placed in a late tile."""
+    B, T, heads, ch = 1, 256, 1, 32
+    q = det_normal((B, ch, T), "rq")
+    k = det_normal((B, ch, T), "rk")
+    v = det_normal((B, ch, T), "rv")
+    k[0, :, 200] = q[0, :, 7] * 6.0
+    for dtype in DTYPES:
+        qq, kk, vv = rnd(q, dtype), rnd(k, dtype), rnd(v, dtype)
+        ref = R.qkv_attention(torch.cat([qq, kk, vv], 1), heads, new_order=True)
+        qk = torch.cat([qq, kk], 1).permute(0, 2, 1).contiguous().to(DEV).to(dtype)
+        out = ops.attention(qk, vv.contiguous().to(DEV).to(dtype), heads)
+        assert rel_l2(out.float().cpu().permute(0, 2, 1), ref) < tol(dtype, f32=1e-5, bf16=1e-2)

@@ -1,0 +1,166 @@
+"""-m gpu: the UNet engine / module classes / DDPM loops against golden vectors produced by the
+real reference (tests/golden/*.npz) and against the CPU oracle.
+
+Tolerances (rel-L2 over the whole output):
+  fp32 engine  (exact-f32 MFMA):   1e-4  per UNet forward   (north_star: "stated fp32 tolerance")
+  bf16 engine  (bf16 storage):     3e-2  per UNet forward   (CPU bf16 autocast of the reference gives 1.6e-2)
+"""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from helpers import (PARAM_SPACE, UNET_CASES, case_inputs, det_normal, det_state_dict, det_uniform, golden_template,
+                     load_golden, rel_l2)
+from gpu_util import DEV
+from oracle import ref_torch as R
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-4
+BF16_TOL = 3e-2
+
+
+def _build(case, dtype):
+    import rho_diffusion_amd as RA
+    from rho_diffusion_amd.models import MultiEmbeddings, UNet
+    kw, xshape, ykind = UNET_CASES[case]
+    model = UNet(**dict(kw), compute_dtype=dtype)
+    if ykind == "multi":
+        model.cond_fn = MultiEmbeddings(parameter_space=PARAM_SPACE, embedding_dim=4 * kw["model_channels"])
+    return model
+
+
+@pytest.mark.parametrize("case", list(UNET_CASES.keys()))
+def test_state_dict_layout_matches_reference(case):
+    g = load_golden("g4_unet.npz")
+    model = _build(case, torch.float32)
+    ours = [f"{k}|{','.join(map(str, v.shape))}" for k, v in model.state_dict().items()]
+    assert ours == [str(s) for s in g[f"{case}/keys"]]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("case", list(UNET_CASES.keys()))
+def test_unet_forward_vs_reference_golden(case, dtype):
+    g = load_golden("g4_unet.npz")
+    model = _build(case, dtype)
+    model.load_state_dict(det_state_dict(golden_template(g, case), case))
+    model = model.to(DEV)
+    cfg, x, t, y = case_inputs(case)
+    with torch.no_grad():
+        pred = model(x.to(DEV), t.to(DEV), y.to(DEV) if y is not None else None)
+    gold = torch.from_numpy(g[f"{case}/pred"])
+    assert tuple(pred.shape) == tuple(gold.shape)
+    assert torch.isfinite(pred).all()
+    err = rel_l2(pred, gold)
+    assert err < (F32_TOL if dtype == torch.float32 else BF16_TOL), f"{case} rel_l2={err:.3e}"
+
+
+def test_reference_smoke_shapes():
+    """The reference's own smoke test (tests/models/test_unet.py:36-56): rand(8,3,24,16), t = arange(8)."""
+    from rho_diffusion_amd.models import UNet
+    model = UNet(data_shape=16, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=2).to(DEV)
+    x = torch.rand(8, 3, 24, 16, device=DEV)
+    with torch.inference_mode():
+        y = model(x, torch.arange(8, device=DEV))
+    assert isinstance(y, torch.Tensor) and tuple(y.shape) == (8, 3, 24, 16)
+    assert not torch.isnan(y).any()
+    assert float(y.abs().max()) == 0.0          # zero_module quirk: a fresh UNetv2 outputs exactly 0
+
+
+def test_modules_vs_reference_golden():
+    """Stand-alone ResBlock / AttentionBlock / Down / Upsample / GroupNorm32 (golden G3)."""
+    from rho_diffusion_amd.layers import GroupNorm32
+    from rho_diffusion_amd.models import AttentionBlock, Downsample, ResBlock, Upsample
+    g = load_golden("g3_modules.npz")
+
+    def fill(mod, salt):
+        mod.load_state_dict(det_state_dict(mod.state_dict(), salt))
+        return mod.to(DEV)
+
+    with torch.no_grad():
+        for name, dims, cin, cout, shape in [("res2d_same", 2, 32, 32, (2, 32, 8, 12)), ("res2d_wide", 2, 32, 64, (2, 32, 8, 12)),
+                                             ("res3d_wide", 3, 64, 32, (2, 64, 4, 6, 8)), ("res3d_same", 3, 32, 32, (1, 32, 5, 4, 8))]:
+            for ssn in (True, False):
+                blk = fill(ResBlock(cin, 128, 0.0, out_channels=cout, dims=dims, use_scale_shift_norm=ssn), name)
+                y = blk(det_normal(shape, name + "x").to(DEV), det_normal((shape[0], 128), name + "emb").to(DEV))
+                assert rel_l2(y, torch.from_numpy(g[f"{name}_ssn{int(ssn)}/y"])) < 5e-5, (name, ssn)
+        for name, c, heads, shape in [("attn2d", 64, 4, (2, 64, 8, 8)), ("attn3d", 64, 2, (2, 64, 4, 8, 8)), ("attn2d_h1", 32, 1, (1, 32, 4, 4))]:
+            for new in (False, True):
+                blk = fill(AttentionBlock(c, num_heads=heads, use_new_attention_order=new), name)
+                y = blk(det_normal(shape, name + "x").to(DEV))
+                assert rel_l2(y, torch.from_numpy(g[f"{name}_new{int(new)}/y"])) < 2e-2, (name, new)   # bf16 kernel
+        for name, dims, c, shape in [("down3d", 3, 32, (2, 32, 4, 8, 8)), ("down2d", 2, 32, (2, 32, 8, 8)), ("down1d", 1, 32, (2, 32, 16))]:
+            x = det_normal(shape, name + "x").to(DEV)
+            y = fill(Downsample(c, True, dims=dims), name)(x)
+            assert rel_l2(y, torch.from_numpy(g[f"{name}/y"])) < 5e-5, name
+            y = fill(Upsample(c, True, dims=dims), name + "up")(x)
+            assert rel_l2(y, torch.from_numpy(g[f"{name}_up/y"])) < 5e-5, name
+        gn = fill(GroupNorm32(32, 64), "gn")
+        y = gn((det_normal((2, 64, 3, 5, 7), "gnx") * 3 + 1.5).to(DEV))
+        assert rel_l2(y, torch.from_numpy(g["gn/y"])) < 5e-5
+
+
+# ----------------------------------------------------------------------------- DDPM loops (golden G5)
+def _ddpm(T, dtype):
+    from rho_diffusion_amd.diffusion import DDPM, LinearSchedule
+    from rho_diffusion_amd.models import UNet
+    g4 = load_golden("g4_unet.npz")
+    kw, xshape, _ = UNET_CASES["tiny2d"]
+    ddpm = DDPM(UNet, dict(kw, compute_dtype=dtype), LinearSchedule(T, 1e-3, 0.02), nn.MSELoss, timesteps=T)
+    ddpm.backbone.load_state_dict(det_state_dict(golden_template(g4, "tiny2d"), "tiny2d"))
+    return ddpm.to(DEV), xshape
+
+
+@pytest.mark.parametrize("T", [50, 100])
+def test_ddpm_forward_process_vs_reference(T):
+    g = load_golden("g5_ddpm.npz")
+    ddpm, xshape = _ddpm(T, torch.float32)
+    x0 = det_uniform(xshape, "x0", 0.0, 1.0).to(DEV)
+    eps = det_normal(xshape, "eps").to(DEV)
+    ddpm.noise = lambda data: eps
+    xt, n = ddpm.forward_process(x0, torch.from_numpy(g[f"T{T}/t"]))
+    assert rel_l2(xt, torch.from_numpy(g[f"T{T}/q_sample"])) < 1e-6
+    assert torch.equal(n, eps)
+
+
+@pytest.mark.parametrize("T", [50, 100])
+def test_ddpm_reverse_process_vs_reference(T):
+    """Ancestral sampling with the reference's noise tape replayed (first draw = x_T, then one z per t > 1)."""
+    g = load_golden("g5_ddpm.npz")
+    ddpm, xshape = _ddpm(T, torch.float32)
+    tape = iter([det_normal(xshape, f"tape{T}_{i}").to(DEV) for i in range(T)])
+    ddpm.noise = lambda data: next(tape).clone()
+    res = ddpm.reverse_process(torch.zeros(xshape, device=DEV), None, t_checkpoints=[0, 1, 2])
+    assert rel_l2(res["denoised"], torch.from_numpy(g[f"T{T}/denoised"])) < 2e-3
+    assert rel_l2(res["buffer"], torch.from_numpy(g[f"T{T}/buffer"])) < 2e-3
+
+
+def test_ddpm_reverse_process_bf16_tracks_fp32():
+    """bf16 engine, teacher-forced short chain (compare short trajectories, not full chains)."""
+    T = 20
+    outs = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        ddpm, xshape = _ddpm(T, dtype)
+        tape = iter([det_normal(xshape, f"tapeb_{i}").to(DEV) for i in range(T)])
+        ddpm.noise = lambda data: next(tape).clone()
+        outs[dtype] = ddpm.reverse_process(torch.zeros(xshape, device=DEV))["denoised"]
+    assert rel_l2(outs[torch.bfloat16], outs[torch.float32]) < 0.15
+
+
+def test_ddpm_noise_is_reproducible_and_normal():
+    ddpm, xshape = _ddpm(50, torch.bfloat16)
+    a = ddpm.noise(torch.empty(4, 1, 64, 64, device=DEV))
+    ddpm._noise_offset = 0
+    b = ddpm.noise(torch.empty(4, 1, 64, 64, device=DEV))
+    assert torch.equal(a, b)
+    assert abs(float(a.mean())) < 0.05 and abs(float(a.std()) - 1) < 0.05
+
+
+def test_product_path_has_no_cpu_fallback():
+    from rho_diffusion_amd.hip import RhoHipError
+    from rho_diffusion_amd.models import UNet
+    kw, xshape, _ = UNET_CASES["tiny2d"]
+    model = UNet(**dict(kw))            # parameters on the CPU
+    with pytest.raises(RhoHipError):
+        model(torch.zeros(xshape), torch.zeros(xshape[0], dtype=torch.long))
