@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""Headline benchmark: DDPM denoising steps/s (and training samples/s once --mode train is
+selected) on 3-D 64^3 spherical-harmonics density fields, UNetv2 (BASELINE.json configs[2]).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  A "step" = one pass of the reverse-process hot path over one batch:
+Philox noise draw, UNetv2 forward (eps prediction), p_sample update, device-side step advance
+(rho_diffusion/diffusion/ddpm.py:195-218).  Sampling shards by independent samples: no data-path
+collective, weak scaling (per-GPU batch fixed).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense peaks, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", choices=["sample", "train"], default="sample")
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[2]: 32)")
+    ap.add_argument("--grid", type=int, default=64)
+    ap.add_argument("--dims", type=int, default=3)
+    ap.add_argument("--mc", type=int, default=64)
+    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def build_model(args, device):
+    """UNetv2 with BASELINE hyper-parameters, default init seed 777, zero-initialised
+    layers re-randomised N(0, 0.02) so kernels see realistic data (a fresh UNetv2 outputs exactly 0)."""
+    from rho_diffusion_amd.diffusion import DDPM, LinearSchedule
+    from rho_diffusion_amd.models import UNet
+    from torch import nn
+    torch.manual_seed(777)
+    kw = dict(data_shape=[args.grid] * args.dims, in_channels=1, out_channels=1, model_channels=args.mc,
+              num_res_blocks=2, channel_mult=(1, 2, 4, 8), attention_resolutions=[16, 8], num_heads=4,
+              use_scale_shift_norm=True, dims=args.dims, activation="SiLU", compute_dtype=args.dtype)
+    ddpm = DDPM(UNet, kw, LinearSchedule(1000, 1e-3, 0.02), nn.MSELoss, timesteps=1000)
+    with torch.no_grad():
+        for p in ddpm.backbone.parameters():
+            if float(p.abs().max()) == 0.0:
+                p.normal_(0.0, 0.02)
+    return ddpm.to(device), kw
+
+
+def cpu_baseline(kw, ddpm, args):
+    """The CPU oracle (fp32, stock PyTorch CPU ops == what the reference executes) timed on this
+    host's cores for a bounded sample: B=1 denoising steps, scaled linearly to the bench batch."""
+    from oracle import ref_torch as R
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    n_threads = max(1, min(avail, 32))      # a GPU box's CPU share; more threads oversubscribe the ATen pool
+    torch.set_num_threads(n_threads)
+    sd = {k: v.detach().float().cpu() for k, v in ddpm.backbone.state_dict().items()}
+    cfg = {k: v for k, v in kw.items() if k != "compute_dtype"}
+    sched = R.linear_schedule(1000, 1e-3, 0.02)
+    shape = (1, 1) + (args.grid,) * args.dims
+    x = torch.randn(shape)
+    z = torch.randn(shape)
+    times = []
+    with torch.no_grad():
+        for i in range(args.cpu_steps + 1):
+            t0 = time.perf_counter()
+            t = 999 - i
+            pred = R.unet_forward(sd, cfg, x, torch.full((1,), t, dtype=torch.long))
+            x = R.p_sample_step(x, pred, t, sched, z)
+            times.append(time.perf_counter() - t0)
+    per_b1 = sum(times[1:]) / max(1, len(times) - 1)
+    return {"value": 1.0 / (per_b1 * args.batch), "unit": "denoising_steps/s", "cores": n_threads, "kind": "port",
+            "sample": f"B=1 of {args.batch}, {args.cpu_steps} timed steps after 1 warm-up ({per_b1:.2f} s per B=1 step), "
+                      f"scaled x{args.batch} in time; fp32 oracle (oracle/ref_torch.py)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    from rho_diffusion_amd.engine import ops
+    ddpm, kw = build_model(args, device)
+    B = args.batch
+    shape = (B, 1) + (args.grid,) * args.dims
+    engine = ddpm.backbone.engine()
+    tables = ddpm.schedule.device_tables(device)
+    ddpm.noise_seed = 777 + rank
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.mode == "sample":
+        x_t = ddpm.noise(torch.empty(shape, device=device))
+        z = torch.empty(shape, dtype=torch.float32, device=device)
+        t_dev = torch.full((1,), 999, dtype=torch.int32, device=device)
+        off_dev = torch.full((1,), 1 << 32, dtype=torch.int64, device=device)
+        n_elem = x_t.numel()
+
+        def step():
+            ops.philox_normal(z, ddpm.noise_seed, 0, offset_dev=off_dev)
+            pred = engine.forward(x_t, None, None, t_scalar_dev=t_dev)
+            ops.p_sample_step(x_t, pred, z, tables["coef"], t_dev)
+            ops.step_advance(t_dev, off_dev, (n_elem + 3) // 4)
+        metric, unit = "denoising_steps_per_sec", "steps/s"
+        units_per_step = 1.0
+    else:
+        raise SystemExit("--mode train: backward kernels are not built yet (DESIGN.md, 'next')")
+
+    if world > 1:   # warm-up collective (cf. xpu.py:374-375), not part of the data path
+        w = torch.ones(8, device=device)
+        dist.all_reduce(w)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(x_t).all(), "non-finite state after the timed steps"
+
+    out = {
+        "metric": metric, "value": world * units_per_step * args.steps / dt, "unit": unit, "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"DDPM reverse step, UNetv2 {args.dims}D {args.grid}^{args.dims} mc={args.mc} "
+                               f"(BASELINE configs[2]), batch {B}/GPU, LinearSchedule(1000,1e-3,0.02)",
+                   "global_batch": B * world, "sample_steps_per_sec": world * B * args.steps / dt,
+                   "parallelism": f"independent samples x{world} (no data-path collective)"},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        plan = next(iter(engine._plans.values()))
+        prof = plan.profile(repeats=3)
+        conv3 = [p for p in prof if p["kind"] == "conv3"]
+        fl = sum(p["flops"] for p in conv3)
+        ms = sum(p["ms"] for p in conv3)
+        tot_ms = sum(p["ms"] for p in prof)
+        by_kind = {}
+        for p in prof:
+            k = by_kind.setdefault(p["kind"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+            k["ms"] += p["ms"]; k["flops"] += p["flops"]; k["bytes"] += p["bytes"]; k["launches"] += 1
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        achieved = fl / (ms * 1e-3) / 1e12
+        out["roofline"] = {
+            "bound": "mfma", "kernel": "k_conv (3x3x3 implicit GEMM, LDS halo tile)", "achieved": achieved, "peak": peak,
+            "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+            "launches_per_step": len(conv3), "avg_launch_ms": ms / max(1, len(conv3)),
+            "algorithmic_flops_per_step": fl, "kernel_ms_per_step": ms, "all_kernels_ms_per_step": tot_ms,
+            "by_kind_ms": {k: round(v["ms"], 3) for k, v in by_kind.items()},
+            "hbm_kernels_GBps": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in by_kind.items()
+                                 if k in ("gn_partial", "pack") and v["ms"] > 0},
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(kw, ddpm, args)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -191,6 +191,7 @@ class _Plan:
         dt = eng.dtype
         dev = eng.device
         self.ops: List[Callable[[int], int]] = []
+        self.info: List[dict] = []     # per launch: kind, algorithmic flops / bytes (for bench roofline)
         self.keep: List[object] = []   # descriptors / tensors referenced by raw pointers
         L = hip.lib()
         B = xshape[0]
@@ -219,6 +220,7 @@ class _Plan:
             args = (ptr(xt), ptr(w), ptr(b), ptr(add), ptr(out), Bn, K, O, int(act_in), int(act_out))
             self.keep.append((xt, w, b, add, out))
             self.ops.append(lambda s, a=args: L.rho_linear(*a, s))
+            self.info.append(dict(kind="linear", flops=2.0 * Bn * K * O, bytes=4.0 * (O * K + Bn * (K + O))))
 
         op_linear(self.sin_in, te0.weight, te0.bias, None, self.emb_h, False, True)
         op_linear(self.emb_h, te2.weight, te2.bias, self.cond, self.emb, False, False)
@@ -246,8 +248,11 @@ class _Plan:
                 stride = self.film.shape[1]
             a1 = (ptr(x1), c1, ptr(x2), c2, hip.dtype_code(dt), N, S, ptr(part))
             a2 = (ptr(part), N, Cc, S, nblk, ptr(norm.weight), ptr(norm.bias), scale, shift, stride, ptr(st), ptr(a), ptr(b))
+            esz = 2 if dt == torch.bfloat16 else 4
             self.ops.append(lambda s, a=a1: L.rho_gn_partial(*a, s))
+            self.info.append(dict(kind="gn_partial", flops=3.0 * N * S * Cc, bytes=float(esz) * N * S * Cc))
             self.ops.append(lambda s, a=a2: L.rho_gn_finalize(*a, s))
+            self.info.append(dict(kind="gn_finalize", flops=0.0, bytes=4.0 * N * Cc * 4))
             return a, b
 
         def conv(x1, x2, cw, *, stride_hw=(1, 1), up_hw=(0, 0), pre=None, pre_silu=False, res=None, res_add=None,
@@ -265,6 +270,14 @@ class _Plan:
                 d.res_add = res_add
             self.keep.append(d)
             self.ops.append(lambda s, d=d: L.rho_conv_nd_fwd(C.byref(d), s))
+            taps = cw.kernel[0] * cw.kernel[1] * cw.kernel[2]
+            esz = 2 if dt == torch.bfloat16 else 4
+            npos_out = N * Do * Ho * Wo
+            npos_in = x1.numel() // x1.shape[-1]
+            self.info.append(dict(
+                kind="conv3" if taps > 1 else "conv1", taps=taps, cin=cw.cin, cout=cout, positions=npos_out,
+                flops=2.0 * npos_out * cout * cw.cin * taps,                       # algorithmic (unpadded) MACs * 2
+                bytes=float(esz) * (npos_in * cw.cin + npos_out * cout * (2 if res is not None else 1) + taps * cout * cw.cin)))
             return y, y2
 
         def resblock(blk, h1, h2):
@@ -291,6 +304,8 @@ class _Plan:
             ao = buf(N, Dd, Hh, Ww, Cc)
             args = (ptr(qk), ptr(vt), ptr(ao), hip.dtype_code(dt), N, T, blk.num_heads, Cc // blk.num_heads)
             self.ops.append(lambda s, a=args: L.rho_attention_fwd(*a, s))
+            esz = 2 if dt == torch.bfloat16 else 4
+            self.info.append(dict(kind="attention", flops=4.0 * N * T * T * Cc, bytes=float(esz) * 4 * N * T * Cc))
             out, _ = conv(ao, None, eng._conv(blk.proj_out), res=xin)
             return out
 
@@ -316,6 +331,7 @@ class _Plan:
         self.x_cl = buf(B, D, H, W, stem.cinp)
         pk = (ptr(self.x_in), ptr(self.x_cl), hip.dtype_code(dt), B, xshape[1], D * H * W, stem.cinp)
         self.ops.append(lambda s, a=pk: L.rho_pack_input(*a, s))
+        self.info.append(dict(kind="pack", flops=0.0, bytes=4.0 * B * xshape[1] * D * H * W + 2.0 * B * D * H * W * stem.cinp))
 
         hs = []
         h = self.x_cl
@@ -357,3 +373,22 @@ class _Plan:
             if rc != 0:
                 check(rc, "UNet plan launch")
         return self.out
+
+    def profile(self, repeats: int = 3) -> List[dict]:
+        """Replay the plan with a HIP event pair around every launch (events recorded on the stream
+        the kernels are launched on) and return per-launch dicts {kind, flops, bytes, ms} (ms = mean over repeats).
+        Inputs are whatever the buffers currently hold."""
+        s = hip.stream()
+        tot = [0.0] * len(self.ops)
+        for _ in range(repeats):
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in self.ops]
+            for op, (e0, e1) in zip(self.ops, evs):
+                e0.record()
+                rc = op(s)
+                e1.record()
+                if rc != 0:
+                    check(rc, "UNet plan launch (profile)")
+            torch.cuda.synchronize()
+            for i, (e0, e1) in enumerate(evs):
+                tot[i] += e0.elapsed_time(e1)
+        return [dict(info, ms=tot[i] / repeats) for i, info in enumerate(self.info)]

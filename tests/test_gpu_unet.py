@@ -137,15 +137,28 @@ def test_ddpm_reverse_process_vs_reference(T):
 
 
 def test_ddpm_reverse_process_bf16_tracks_fp32():
-    """bf16 engine, teacher-forced short chain (compare short trajectories, not full chains)."""
+    """bf16 engine vs fp32 engine, teacher-forced along the fp32 trajectory (bf16 drift is
+    compared per step, not over a free-running chaotic chain): at every step both engines see the
+    same x_t and their eps predictions must agree to the bf16 forward tolerance."""
     T = 20
-    outs = {}
-    for dtype in (torch.float32, torch.bfloat16):
-        ddpm, xshape = _ddpm(T, dtype)
-        tape = iter([det_normal(xshape, f"tapeb_{i}").to(DEV) for i in range(T)])
-        ddpm.noise = lambda data: next(tape).clone()
-        outs[dtype] = ddpm.reverse_process(torch.zeros(xshape, device=DEV))["denoised"]
-    assert rel_l2(outs[torch.bfloat16], outs[torch.float32]) < 0.15
+    d32, xshape = _ddpm(T, torch.float32)
+    d16, _ = _ddpm(T, torch.bfloat16)
+    tape = iter([det_normal(xshape, f"tapeb_{i}").to(DEV) for i in range(T)])
+    d32.noise = lambda data: next(tape).clone()
+    worst = 0.0
+    orig = d32.backbone.engine().forward
+
+    def both(x, ts, y=None, t_scalar_dev=None):
+        nonlocal worst
+        p32 = orig(x, ts, y, t_scalar_dev=t_scalar_dev).clone()
+        p16 = d16.backbone.engine().forward(x, ts, y, t_scalar_dev=t_scalar_dev)
+        worst = max(worst, rel_l2(p16, p32))
+        return p32
+
+    d32.backbone.engine().forward = both
+    out = d32.reverse_process(torch.zeros(xshape, device=DEV))["denoised"]
+    assert torch.isfinite(out).all()
+    assert worst < BF16_TOL, worst
 
 
 def test_ddpm_noise_is_reproducible_and_normal():
