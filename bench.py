@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--dump-ops", default=None, help="write the per-launch profile (kind, shape, ms, TFLOP/s) to this file")
     return ap.parse_args()
 
 
@@ -173,6 +174,13 @@ def main():
         for p in prof:
             k = by_kind.setdefault(p["kind"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
             k["ms"] += p["ms"]; k["flops"] += p["flops"]; k["bytes"] += p["bytes"]; k["launches"] += 1
+        if args.dump_ops:
+            with open(args.dump_ops, "w") as f:
+                for i, p_ in enumerate(prof):
+                    tf = p_["flops"] / (p_["ms"] * 1e-3) / 1e12 if p_["ms"] > 0 else 0.0
+                    gb = p_["bytes"] / (p_["ms"] * 1e-3) / 1e9 if p_["ms"] > 0 else 0.0
+                    f.write(f"{i:4d} {p_['kind']:12s} ms={p_['ms']:8.3f} TF/s={tf:8.1f} GB/s={gb:8.1f} "
+                            f"cin={p_.get('cin', '')} cout={p_.get('cout', '')} taps={p_.get('taps', '')} pos={p_.get('positions', '')}\n")
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         achieved = fl / (ms * 1e-3) / 1e12
         out["roofline"] = {
