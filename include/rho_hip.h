@@ -149,6 +149,11 @@ typedef struct rho_conv_desc {
     int32_t up_h, up_w;    /* nearest x2 upsample folded into the loader (unet_v2.py:122-131) */
     int32_t pre_silu;      /* apply SiLU after the affine prologue */
     int32_t res_add_stride;
+    /* --- backward-data use of the same kernel (dgrad = conv of dY with flipped, transposed weights) */
+    int32_t y2_cl;         /* 1: y2 is channels-last [.., cout-split] (gradient of the 2nd concat source) */
+    int32_t zs_h, zs_w;    /* input is dY of a stride-2 conv, read zero-stuffed: virtual extent out_h/out_w */
+    int32_t out_h, out_w;  /* forward-conv input extents (only with zs_*) */
+    const void* res2;      /* optional residual for the y2 region (channels-last): in-place grad accumulation */
 } rho_conv_desc;
 
 /* n-D convolution, zero padding k/2, as an LDS-halo-staged implicit GEMM on MFMA.
@@ -164,9 +169,69 @@ int rho_conv_nd_fwd(const rho_conv_desc* desc, void* stream);
  * unet_v2.py:365-436, with the head order resolved at weight-prep time).
  * qk: channels-last [B, T, 2C] (q of head h at h*ch, k at C + h*ch); vt: channel-major
  * [B, C, T]; out: channels-last [B, T, C].  logits = (q.k) * ch^-0.5 (== scaling q and k by
- * ch^-0.25 each, :385,:420).  ch in {16, 32, 64, 128, 256}. */
-int rho_attention_fwd(const void* qk, const void* vt, void* out, int dtype, int64_t batch, int64_t t,
+ * ch^-0.25 each, :385,:420).  ch in {16, 32, 64, 128, 256}.  lse (optional, float32 [B, heads, T]) receives the
+ * base-2 log-sum-exp of the scaled logits per query, which rho_attention_bwd recomputes from. */
+int rho_attention_fwd(const void* qk, const void* vt, void* out, float* lse, int dtype, int64_t batch, int64_t t,
                       int64_t heads, int64_t ch, void* stream);
+
+/* ================================================================== backward (training) */
+
+/* Weight gradient of rho_conv_nd_fwd (autograd of conv_nd, layers.py:77-88): desc describes the FORWARD
+ * conv (inputs + prologue, which is recomputed in the loader); dy is its output gradient, channels-last with
+ * row width dy_width (>= cout, padding channels zero); dw is an fp32 buffer [taps][coutp][c1+c2] that the
+ * call accumulates into with fp32 atomics (zero it first).  up_h/up_w unsupported: pass the materialised
+ * upsampled input (rho_upsample2x). */
+int rho_conv_nd_wgrad(const rho_conv_desc* desc, const void* dy, int64_t dy_width, float* dw, void* stream);
+
+/* dw buffer -> parameter-gradient layout [cout][cin][taps] float32 (undoing the qkv row gather). */
+int rho_wgrad_finalize(const float* dw, float* grad, int64_t cout, int64_t cin, int64_t taps, int64_t coutp,
+                       int64_t cin_buf, const int32_t* row_src, int accumulate, void* stream);
+
+/* Weights for the data gradient: out[tap'][ci][co'] = w[src(co')][ci][taps-1-tap'] so that rho_conv_nd_fwd
+ * applied to dY yields dX.  rows padded to rowsp, cols to colsp. */
+int rho_prep_conv_weight_dgrad(const float* w, void* out, int dtype, int64_t cout, int64_t cin, int64_t taps,
+                               int64_t rowsp, int64_t colsp, const int32_t* col_src, void* stream);
+
+/* Backward of act(GroupNorm32(x) * (1 + scale) + shift) (layers.py:71-74 + unet_v2.py:285-289), recomputed
+ * from x, the saved stats and the folded affine (a, b):
+ *   reduce  : per-(n, c) sums of g*act'(u) and g*act'(u)*xhat            (one pass over g and x)
+ *   finalize: dgamma / dbeta (summed over samples, optionally accumulated), FiLM gradients dscale / dshift
+ *             ([N, C] at row stride dfilm_stride), and the coefficients cA [N,C], cP / cQ [N,32] of pass 3;
+ *             work_nc2 is float32 [2][N][C] scratch
+ *   apply   : dx = cA*g*act'(u) + cP + cQ*x, written (or accumulated) into the one or two source gradients. */
+int rho_gn_bwd_reduce(const void* g, const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t n,
+                      int64_t s, const float* a, const float* b, const float* stats, int pre_silu, float* partials,
+                      void* stream);
+int rho_gn_bwd_finalize(const float* partials, int64_t n, int64_t c, int64_t s, int64_t nblk, const float* gamma,
+                        const float* beta, const float* scale, int64_t film_stride, const float* stats,
+                        float* work_nc2, float* dgamma, float* dbeta, int accumulate, float* dscale, float* dshift,
+                        int64_t dfilm_stride, float* cA, float* cP, float* cQ, void* stream);
+int rho_gn_bwd_apply(const void* g, const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t n,
+                     int64_t s, const float* a, const float* b, int pre_silu, const float* cA, const float* cP,
+                     const float* cQ, void* dx1, void* dx2, int acc1, int acc2, void* stream);
+
+/* Channel sums of a channels-last tensor (conv bias gradients; additive-embedding gradients):
+ * out_nc[n*nc_stride + c] (+)= sum_pos x[n,pos,c];  out_c[c] (+)= sum_n out_nc[n][c] (optional).
+ * partials: scratch sized like rho_gn_partial's. */
+int rho_chan_sum(const void* x, int dtype, int64_t n, int64_t s, int64_t c, float* partials, float* out_nc,
+                 int64_t nc_stride, int acc_nc, float* out_c, int acc_c, void* stream);
+
+/* Nearest x2 upsample (materialised only for the wgrad of Upsample.conv) and its backward (2x2 / 1x2 sum). */
+int rho_upsample2x(const void* x, void* y, int dtype, int64_t n_times_d, int64_t h, int64_t w, int64_t c, int up_h,
+                   int up_w, void* stream);
+int rho_pool2x_sum(const void* dy, void* dx, int dtype, int64_t n_times_d, int64_t h, int64_t w, int64_t c, int up_h,
+                   int up_w, int accumulate, void* stream);
+
+/* Backward of rho_linear: dw[o,k] (+)= sum_b dout[b,o] act(x[b,k]); db[o] (+)= sum_b dout[b,o];
+ * dx[b,k] (+)= act'(x[b,k]) sum_o dout[b,o] w[o,k].  dw/db/dx may be NULL. */
+int rho_linear_bwd(const float* dout, const float* x, const float* w, float* dw, float* db, float* dx, int64_t batch,
+                   int64_t in_dim, int64_t out_dim, int act_in, int acc_params, int acc_dx, void* stream);
+
+/* Backward of rho_attention_fwd (recompute from lse).  o / dout channels-last [B,T,C]; delta_ws float32
+ * [B,heads,T] scratch; outputs dqk [B,T,2C] (dq | dk) and dv [B,T,C], channels-last in `dtype`. */
+int rho_attention_bwd(const void* qk, const void* vt, const void* o, const void* dout, const float* lse,
+                      float* delta_ws, void* dqk, void* dv, int dtype, int64_t batch, int64_t t, int64_t heads,
+                      int64_t ch, void* stream);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,8 @@
 
 template <int CH, int KT>  // KT keys per LDS tile (64; 32 for CH = 256 to stay inside static LDS)
 __global__ __launch_bounds__(256) void k_attn_bf16(const bf16_raw* __restrict__ qk, const bf16_raw* __restrict__ vt,
-                                                   bf16_raw* __restrict__ out, int T, int C, float scale_log2e) {
+                                                   bf16_raw* __restrict__ out, int T, int C, float scale_log2e,
+                                                   float* __restrict__ lse) {
     constexpr int KP = CH * 2 + 16;   // K tile row pitch (bytes): odd number of 16-B slots => conflict-free
     constexpr int VP = KT * 2 + 16;   // V^T tile row pitch
     constexpr int NKK = CH / 16;      // k-steps of the QK^T contraction
@@ -150,6 +151,8 @@ __global__ __launch_bounds__(256) void k_attn_bf16(const bf16_raw* __restrict__ 
     // ---- normalise and store: lane holds channels 32*ct + 8*rg + 4*half + {0..3} of query qi
     if (qi < T) {
         const float inv = 1.0f / l_run;
+        // base-2 log-sum-exp of the scaled logits, saved for the backward recompute
+        if (lse != nullptr && half == 0) lse[((size_t)b * gridDim.y + h) * T + qi] = m_run + log2f(l_run);
         bf16_raw* op = out + ((size_t)b * T + qi) * C + (size_t)h * CH;
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
@@ -171,7 +174,8 @@ __global__ __launch_bounds__(256) void k_attn_bf16(const bf16_raw* __restrict__ 
 // 64 queries per workgroup; 4 lanes share a query, each owning CH/4 channels of q and of the output.
 template <int CH, int KT>
 __global__ __launch_bounds__(256) void k_attn_f32(const float* __restrict__ qk, const float* __restrict__ vt,
-                                                  float* __restrict__ out, int T, int C, float scale_log2e) {
+                                                  float* __restrict__ out, int T, int C, float scale_log2e,
+                                                  float* __restrict__ lse) {
     constexpr int CP = CH / 4;
     __shared__ float k_lds[KT][CH + 1];
     __shared__ float v_lds[KT][CH + 1];
@@ -231,14 +235,15 @@ __global__ __launch_bounds__(256) void k_attn_f32(const float* __restrict__ qk, 
     }
     if (qi < T) {
         const float inv = 1.0f / l_run;
+        if (lse != nullptr && part == 0) lse[((size_t)b * gridDim.y + h) * T + qi] = m_run + log2f(l_run);
         float* op = out + ((size_t)b * T + qi) * C + (size_t)h * CH + part * CP;
 #pragma unroll
         for (int c = 0; c < CP; ++c) op[c] = o[c] * inv;
     }
 }
 
-extern "C" int rho_attention_fwd(const void* qk, const void* vt, void* out, int dtype, int64_t batch, int64_t t, int64_t heads,
-                                 int64_t ch, void* stream) {
+extern "C" int rho_attention_fwd(const void* qk, const void* vt, void* out, float* lse, int dtype, int64_t batch, int64_t t,
+                                 int64_t heads, int64_t ch, void* stream) {
     if (!qk || !vt || !out || batch <= 0 || t <= 0 || heads <= 0) return RHO_E_ARG;
     if (dtype != RHO_BF16 && dtype != RHO_F32) return RHO_E_ARG;
     const int C = (int)(heads * ch);
@@ -249,7 +254,7 @@ extern "C" int rho_attention_fwd(const void* qk, const void* vt, void* out, int 
 #define RHO_ATT32(chv, ktv)                                                                                             \
     case chv:                                                                                                           \
         hipLaunchKernelGGL((k_attn_f32<chv, ktv>), grid, block, 0, st, (const float*)qk, (const float*)vt, (float*)out, \
-                           (int)t, C, sl2);                                                                             \
+                           (int)t, C, sl2, lse);                                                                        \
         break;
         switch (ch) {
             RHO_ATT32(16, 64)
@@ -268,7 +273,7 @@ extern "C" int rho_attention_fwd(const void* qk, const void* vt, void* out, int 
 #define RHO_ATT(chv)                                                                                                      \
     case chv:                                                                                                             \
         hipLaunchKernelGGL((k_attn_bf16<chv, (chv >= 256 ? 32 : 64)>), grid, block, 0, st, (const bf16_raw*)qk,              \
-                           (const bf16_raw*)vt, (bf16_raw*)out, (int)t, C, sl2);                                          \
+                           (const bf16_raw*)vt, (bf16_raw*)out, (int)t, C, sl2, lse);                                     \
         break;
     switch (ch) {
         RHO_ATT(16)

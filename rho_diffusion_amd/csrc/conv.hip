@@ -18,9 +18,7 @@
 //   * Weights ([tap][cout][cin], prepared once) stream through a 2-deep LDS ring, one tap ahead.
 //
 // Replaces conv_nd at every call site of rho_diffusion/models/unet_v2.py (see include/rho_hip.h).
-#include "common.h"
-
-#define PITCH 80  // bytes per LDS row (64 payload + 16 pad)
+#include "conv_common.h"
 
 struct ConvK {
     const char* x1;
@@ -42,82 +40,11 @@ struct ConvK {
     int TD, TH, TW, ID, IH, IW, NP;
     int tiles_h, tiles_w;
     int res_add_stride;
+    int y2_cl;            // y2 is channels-last [.., cout - split] (dgrad of a concatenated input) instead of channel-major
+    const char* res2;     // residual for the y2 region (channels-last only): in-place gradient accumulation
+    int zs_h, zs_w;       // zero-stuffed input (dgrad of a stride-2 conv): virtual extent H/W, source extent Hs/Ws
+    int Hs, Ws;
 };
-
-template <typename T>
-struct ET;
-template <>
-struct ET<bf16_raw> {
-    static constexpr int CK = 32;  // channels per 64-byte chunk
-    static constexpr int PE = 8;   // elements per 16-byte piece
-};
-template <>
-struct ET<float> {
-    static constexpr int CK = 16;
-    static constexpr int PE = 4;
-};
-
-// y = act(a*x+b) on one 16-byte piece
-template <typename T>
-__device__ __forceinline__ uint4 apply_pre(uint4 v, const float* __restrict__ a, const float* __restrict__ b, int silu);
-
-template <>
-__device__ __forceinline__ uint4 apply_pre<bf16_raw>(uint4 v, const float* __restrict__ a, const float* __restrict__ b, int silu) {
-    const float4 a0 = *reinterpret_cast<const float4*>(a), a1 = *reinterpret_cast<const float4*>(a + 4);
-    const float4 b0 = *reinterpret_cast<const float4*>(b), b1 = *reinterpret_cast<const float4*>(b + 4);
-    float f[8];
-    f[0] = fmaf(a0.x, __uint_as_float(v.x << 16), b0.x);
-    f[1] = fmaf(a0.y, __uint_as_float(v.x & 0xFFFF0000u), b0.y);
-    f[2] = fmaf(a0.z, __uint_as_float(v.y << 16), b0.z);
-    f[3] = fmaf(a0.w, __uint_as_float(v.y & 0xFFFF0000u), b0.w);
-    f[4] = fmaf(a1.x, __uint_as_float(v.z << 16), b1.x);
-    f[5] = fmaf(a1.y, __uint_as_float(v.z & 0xFFFF0000u), b1.y);
-    f[6] = fmaf(a1.z, __uint_as_float(v.w << 16), b1.z);
-    f[7] = fmaf(a1.w, __uint_as_float(v.w & 0xFFFF0000u), b1.w);
-    if (silu) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
-    }
-    uint4 r;
-    r.x = pack_bf16x2(f[0], f[1]);
-    r.y = pack_bf16x2(f[2], f[3]);
-    r.z = pack_bf16x2(f[4], f[5]);
-    r.w = pack_bf16x2(f[6], f[7]);
-    return r;
-}
-
-template <>
-__device__ __forceinline__ uint4 apply_pre<float>(uint4 v, const float* __restrict__ a, const float* __restrict__ b, int silu) {
-    const float4 a0 = *reinterpret_cast<const float4*>(a);
-    const float4 b0 = *reinterpret_cast<const float4*>(b);
-    float f[4];
-    f[0] = fmaf(a0.x, __uint_as_float(v.x), b0.x);
-    f[1] = fmaf(a0.y, __uint_as_float(v.y), b0.y);
-    f[2] = fmaf(a0.z, __uint_as_float(v.z), b0.z);
-    f[3] = fmaf(a0.w, __uint_as_float(v.w), b0.w);
-    if (silu) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) f[j] = silu_f(f[j]);
-    }
-    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
-}
-
-template <typename T>
-__device__ __forceinline__ void mma_step(const uint4& a, const uint4& b, f32x16_t& acc);
-
-template <>
-__device__ __forceinline__ void mma_step<bf16_raw>(const uint4& a, const uint4& b, f32x16_t& acc) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
-}
-template <>
-__device__ __forceinline__ void mma_step<float>(const uint4& a, const uint4& b, f32x16_t& acc) {
-    // lanes 0-31 carry channels {0,1,2,3} of the 8-channel group, lanes 32-63 channels {4,5,6,7};
-    // MFMA #q contracts the channel pair (q, 4+q): any K permutation is valid as A and B agree.
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
-}
 
 template <typename T, int KD, int KH, int KW, int BM, int MAXP>
 __global__ __launch_bounds__(256) void k_conv(const ConvK p) {
@@ -165,9 +92,13 @@ __global__ __launch_bounds__(256) void k_conv(const ConvK p) {
                 const int r = hp - id * ihw;
                 const int ih = r / p.IW;
                 const int iw = r - ih * p.IW;
-                const int gd = gd_base + id, gh = gh_base + ih, gw = gw_base + iw;
-                if (gd >= 0 && gd < p.D && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W) {
-                    pos = ((n * p.D + gd) * p.H + gh) * p.W + gw;
+                const int gd = gd_base + id;
+                int gh = gh_base + ih, gw = gw_base + iw;
+                bool ok = gd >= 0 && gd < p.D && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
+                if (p.zs_h) { ok = ok && ((gh & 1) == 0) && ((gh >> 1) < p.Hs); gh >>= 1; }
+                if (p.zs_w) { ok = ok && ((gw & 1) == 0) && ((gw >> 1) < p.Ws); gw >>= 1; }
+                if (ok) {
+                    pos = ((n * p.D + gd) * p.Hs + gh) * p.Ws + gw;
                     if constexpr (KD != 3) smp = (int)((long long)pos / p.S_in);
                 } else {
                     pos = -1;
@@ -367,6 +298,25 @@ __global__ __launch_bounds__(256) void k_conv(const ConvK p) {
                         }
                         *reinterpret_cast<float4*>(p.y + eo * 4) = make_float4(v0, v1, v2, v3);
                     }
+                } else if (p.y2_cl) {
+                    const int w2 = p.cout - p.split;
+                    const size_t eo = (size_t)L * w2 + (co - p.split);
+                    if (co < p.cout) {                 // widths are multiples of 4: a 4-channel piece is all in or all out
+                        if constexpr (sizeof(T) == 2) {
+                            if (p.res2 != nullptr) {
+                                const uint2 r = *reinterpret_cast<const uint2*>(p.res2 + eo * 2);
+                                v0 += __uint_as_float(r.x << 16); v1 += __uint_as_float(r.x & 0xFFFF0000u);
+                                v2 += __uint_as_float(r.y << 16); v3 += __uint_as_float(r.y & 0xFFFF0000u);
+                            }
+                            *reinterpret_cast<uint2*>(p.y2 + eo * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                        } else {
+                            if (p.res2 != nullptr) {
+                                const float4 r = *reinterpret_cast<const float4*>(p.res2 + eo * 4);
+                                v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
+                            }
+                            *reinterpret_cast<float4*>(p.y2 + eo * 4) = make_float4(v0, v1, v2, v3);
+                        }
+                    }
                 } else {
                     const float vv[4] = {v0, v1, v2, v3};
 #pragma unroll
@@ -388,40 +338,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvK p) {
 // ------------------------------------------------------------------------------------------ host
 namespace {
 
-struct TileChoice {
-    int TD, TH, TW, ID, IH, IW, NP;
-    long long tiles;
-    bool ok;
-};
-
-inline int cdiv(int a, int b) { return (a + b - 1) / b; }
-
-// pick the 256-position output tile: fewest tiles first, then the smallest halo, then the widest W
-TileChoice choose_tile(const rho_conv_desc& d, int Dm, int Do, int Ho, int Wo, int np_cap) {
-    TileChoice best{};
-    best.ok = false;
-    double best_cost = 1e300;
-    for (int TD = 1; TD <= 256; TD *= 2)
-        for (int TH = 1; TH * TD <= 256; TH *= 2) {
-            const int TW = 256 / (TD * TH);
-            if (d.up_h && TH < 2) continue;
-            if (d.up_w && TW < 2) continue;
-            const int ID = TD + (d.kd - 1);
-            const int IH = d.up_h ? TH / 2 + 2 : (TH - 1) * d.sh + d.kh;
-            const int IW = d.up_w ? TW / 2 + 2 : (TW - 1) * d.sw + d.kw;
-            const int NP = ID * IH * IW;
-            if (NP > np_cap) continue;
-            const long long tiles = (long long)cdiv(Do, TD) * cdiv(Ho, TH) * cdiv(Wo, TW);
-            // cost model: per tile, staging ~ NP rows and taps*256 MFMA columns
-            const double cost = (double)tiles * (NP * 1.5 + 256.0 * d.kd * d.kh * d.kw) - 1e-3 * TW;
-            if (cost < best_cost) {
-                best_cost = cost;
-                best = TileChoice{TD, TH, TW, ID, IH, IW, NP, tiles, true};
-            }
-        }
-    (void)Dm;
-    return best;
-}
+using namespace rho_conv;
 
 template <typename T, int KD, int KH, int KW, int BM, int MAXP>
 int launch_one(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
@@ -472,16 +389,20 @@ extern "C" int rho_conv_nd_fwd(const rho_conv_desc* dp, void* stream) {
     if (d.cout <= 0 || d.coutp < d.cout || d.coutp % 32 || d.split < 0 || d.split > d.cout || d.split % 32) return RHO_E_ARG;
     if (d.split > 0 && !d.y) return RHO_E_ARG;
     if (d.split < d.cout && !d.y2) return RHO_E_ARG;
-    if (d.split < d.cout && d.split > 0 && d.coutp != d.cout) return RHO_E_ARG;  // mixed layouts need exact tiling
+    if (d.split < d.cout && d.split > 0 && d.coutp != d.cout && !d.y2_cl) return RHO_E_ARG;  // mixed layouts need exact tiling
+    if (d.y2_cl && ((d.cout - d.split) % 4 != 0)) return RHO_E_ALIGN;
+    if ((d.zs_h || d.zs_w) && (d.up_h || d.up_w || d.sh != 1 || d.sw != 1 || d.out_h <= 0 || d.out_w <= 0)) return RHO_E_ARG;
     if (d.split == d.cout && d.coutp != d.cout) return RHO_E_ARG;               // channels-last rows are not padded
     if ((d.sh != 1 && d.sh != 2) || (d.sw != 1 && d.sw != 2)) return RHO_E_ARG;
     if ((d.up_h && d.sh != 1) || (d.up_w && d.sw != 1)) return RHO_E_ARG;
     if ((d.up_h && d.kh != 3) || (d.up_w && d.kw != 3)) return RHO_E_ARG;
     if (d.n <= 0 || d.d <= 0 || d.h <= 0 || d.w_ <= 0) return RHO_E_ARG;
 
-    // output extents per sample (padding k/2)
-    const int ho = d.up_h ? d.h * 2 : (d.h + 2 * (d.kh / 2) - d.kh) / d.sh + 1;
-    const int wo = d.up_w ? d.w_ * 2 : (d.w_ + 2 * (d.kw / 2) - d.kw) / d.sw + 1;
+    // output extents per sample (padding k/2).  Zero-stuffed input (dgrad of a stride-2 conv): the
+    // virtual input and the output both have the forward conv's input extent out_h / out_w.
+    const int hv = d.zs_h ? d.out_h : d.h, wv = d.zs_w ? d.out_w : d.w_;   // virtual input extents
+    const int ho = d.up_h ? d.h * 2 : (hv + 2 * (d.kh / 2) - d.kh) / d.sh + 1;
+    const int wo = d.up_w ? d.w_ * 2 : (wv + 2 * (d.kw / 2) - d.kw) / d.sw + 1;
     const int dout = d.d;
 
     // axes that carry no kernel extent are merged with the batch so tiles stay full:
@@ -494,13 +415,18 @@ extern "C" int rho_conv_nd_fwd(const rho_conv_desc* dp, void* stream) {
         k.Do = 1; k.Ho = 1; k.Wo = k.W;
         gridz = 1;
     } else if (d.kd == 1) {
-        k.D = d.n * d.d; k.H = d.h; k.W = d.w_;
+        k.D = d.n * d.d; k.H = hv; k.W = wv;
         k.Do = k.D; k.Ho = ho; k.Wo = wo;
         gridz = 1;
     } else {
-        k.D = d.d; k.H = d.h; k.W = d.w_;
+        k.D = d.d; k.H = hv; k.W = wv;
         k.Do = dout; k.Ho = ho; k.Wo = wo;
     }
+    k.Hs = k.H; k.Ws = k.W;
+    if (d.zs_h) k.Hs = d.h;
+    if (d.zs_w) k.Ws = d.w_;
+    k.zs_h = d.zs_h; k.zs_w = d.zs_w;
+    k.y2_cl = d.y2_cl; k.res2 = (const char*)d.res2;
     if ((long long)d.n * d.d * d.h * d.w_ >= (1LL << 31) || (long long)d.n * dout * ho * wo >= (1LL << 31)) return RHO_E_SHAPE;
     k.S_in = (long long)d.d * d.h * d.w_;
     k.S_out = (long long)dout * ho * wo;

@@ -376,3 +376,154 @@ extern "C" int rho_prep_conv_weight(const float* w, void* out, int dtype, int64_
     RHO_LAUNCH_CHECK();
     return 0;
 }
+
+// ================================================================================================ backward helpers
+
+// dgrad weights: out[tap'][ci][co'] = w[src(co')][ci][taps-1-tap']  (flipped taps, transposed channels), so that the
+// FORWARD kernel run on dY computes dX (autograd of conv_nd).  rows padded to rowsp (multiple of 32), cols to colsp.
+template <typename T>
+__global__ __launch_bounds__(256) void k_prep_w_dgrad(const float* __restrict__ w, T* __restrict__ out, int64_t cout, int64_t cin,
+                                                      int64_t taps, int64_t rowsp, int64_t colsp, const int32_t* __restrict__ col_src) {
+    const int64_t total = taps * rowsp * colsp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t col = i % colsp;            // original output channel (possibly permuted)
+        const int64_t row = (i / colsp) % rowsp;  // original input channel
+        const int64_t tap = i / (colsp * rowsp);
+        int64_t src = col_src ? (col < cout ? (int64_t)col_src[col] : -1) : (col < cout ? col : -1);
+        float v = 0.0f;
+        if (src >= 0 && src < cout && row < cin) v = w[(src * cin + row) * taps + (taps - 1 - tap)];
+        out[i] = cvt_out<T>(v);
+    }
+}
+
+extern "C" int rho_prep_conv_weight_dgrad(const float* w, void* out, int dtype, int64_t cout, int64_t cin, int64_t taps,
+                                          int64_t rowsp, int64_t colsp, const int32_t* col_src, void* stream) {
+    if (!w || !out || cout <= 0 || cin <= 0 || taps <= 0 || rowsp < cin || colsp < cout) return RHO_E_ARG;
+    dim3 grid(grid_for(taps * rowsp * colsp, 256)), block(256);
+    if (dtype == RHO_BF16)
+        hipLaunchKernelGGL(k_prep_w_dgrad<bf16_raw>, grid, block, 0, as_stream(stream), w, (bf16_raw*)out, cout, cin, taps, rowsp, colsp, col_src);
+    else if (dtype == RHO_F32)
+        hipLaunchKernelGGL(k_prep_w_dgrad<float>, grid, block, 0, as_stream(stream), w, (float*)out, cout, cin, taps, rowsp, colsp, col_src);
+    else
+        return RHO_E_ARG;
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
+// nearest x2 on H and/or W of a channels-last tensor, 16-byte pieces (materialised only for the wgrad of Upsample.conv)
+__global__ __launch_bounds__(256) void k_upsample2x(const uint4* __restrict__ x, uint4* __restrict__ y, int64_t nd, int h, int w,
+                                                    int cpieces, int uh, int uw) {
+    const int ho = uh ? 2 * h : h, wo = uw ? 2 * w : w;
+    const int64_t total = nd * ho * wo * cpieces;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cp = (int)(i % cpieces);
+        int64_t r = i / cpieces;
+        const int ow = (int)(r % wo); r /= wo;
+        const int oh = (int)(r % ho); r /= ho;
+        const int ih = uh ? oh >> 1 : oh, iw = uw ? ow >> 1 : ow;
+        y[i] = x[((r * h + ih) * w + iw) * cpieces + cp];
+    }
+}
+
+extern "C" int rho_upsample2x(const void* x, void* y, int dtype, int64_t n_times_d, int64_t h, int64_t w, int64_t c, int up_h,
+                              int up_w, void* stream) {
+    const int esz = dtype == RHO_BF16 ? 2 : 4;
+    if (!x || !y || n_times_d <= 0 || h <= 0 || w <= 0 || c <= 0 || (c * esz) % 16) return RHO_E_ARG;
+    const int cp = (int)(c * esz / 16);
+    const int64_t total = n_times_d * (up_h ? 2 * h : h) * (up_w ? 2 * w : w) * cp;
+    hipLaunchKernelGGL(k_upsample2x, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), (const uint4*)x, (uint4*)y, n_times_d,
+                       (int)h, (int)w, cp, up_h, up_w);
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
+// dx[.., h, w, c] (+)= sum over the 2x2 (or 1x2) children of dy: backward of the nearest upsample
+template <typename T>
+__global__ __launch_bounds__(256) void k_pool2x_sum(const T* __restrict__ dy, T* __restrict__ dx, int64_t nd, int h, int w, int c,
+                                                    int uh, int uw, int accumulate) {
+    const int ho = uh ? 2 * h : h, wo = uw ? 2 * w : w;
+    const int64_t total = nd * h * w * c;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % c);
+        int64_t r = i / c;
+        const int iw = (int)(r % w); r /= w;
+        const int ih = (int)(r % h); r /= h;
+        float acc = 0.0f;
+        for (int a = 0; a <= uh; ++a)
+            for (int b = 0; b <= uw; ++b) {
+                const int64_t o = ((r * ho + (uh ? 2 * ih + a : ih)) * wo + (uw ? 2 * iw + b : iw)) * c + ch;
+                if constexpr (sizeof(T) == 2) acc += bf16_to_f32(dy[o]); else acc += dy[o];
+            }
+        if (accumulate) {
+            if constexpr (sizeof(T) == 2) acc += bf16_to_f32(dx[i]); else acc += dx[i];
+        }
+        dx[i] = cvt_out<T>(acc);
+    }
+}
+
+extern "C" int rho_pool2x_sum(const void* dy, void* dx, int dtype, int64_t n_times_d, int64_t h, int64_t w, int64_t c, int up_h,
+                              int up_w, int accumulate, void* stream) {
+    if (!dy || !dx || n_times_d <= 0 || h <= 0 || w <= 0 || c <= 0) return RHO_E_ARG;
+    dim3 grid(grid_for(n_times_d * h * w * c, 256)), block(256);
+    if (dtype == RHO_BF16)
+        hipLaunchKernelGGL(k_pool2x_sum<bf16_raw>, grid, block, 0, as_stream(stream), (const bf16_raw*)dy, (bf16_raw*)dx, n_times_d, (int)h,
+                           (int)w, (int)c, up_h, up_w, accumulate);
+    else if (dtype == RHO_F32)
+        hipLaunchKernelGGL(k_pool2x_sum<float>, grid, block, 0, as_stream(stream), (const float*)dy, (float*)dx, n_times_d, (int)h, (int)w,
+                           (int)c, up_h, up_w, accumulate);
+    else
+        return RHO_E_ARG;
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
+// Backward of rho_linear (out = W act(x) + b [+ add]):  dW[o,k] (+)= sum_b dout[b,o] act(x[b,k]),  db[o] (+)= sum_b dout[b,o]
+__global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ dout, const float* __restrict__ x,
+                                                      float* __restrict__ dw, float* __restrict__ db, int batch, int in_dim,
+                                                      int out_dim, int act_in, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)out_dim * in_dim) return;
+    const int o = (int)(i / in_dim), k = (int)(i % in_dim);
+    float acc = 0.0f, accb = 0.0f;
+    for (int b = 0; b < batch; ++b) {
+        float xv = x[(int64_t)b * in_dim + k];
+        if (act_in) xv = xv / (1.0f + expf(-xv));
+        const float g = dout[(int64_t)b * out_dim + o];
+        acc = fmaf(g, xv, acc);
+        accb += g;
+    }
+    dw[i] = accumulate ? dw[i] + acc : acc;
+    if (k == 0 && db) db[o] = accumulate ? db[o] + accb : accb;
+}
+
+// dx[b,k] (+)= act'(x[b,k]) * sum_o dout[b,o] W[o,k]
+__global__ __launch_bounds__(256) void k_linear_bwd_x(const float* __restrict__ dout, const float* __restrict__ w,
+                                                      const float* __restrict__ x, float* __restrict__ dx, int batch, int in_dim,
+                                                      int out_dim, int act_in, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)batch * in_dim) return;
+    const int b = (int)(i / in_dim), k = (int)(i % in_dim);
+    float acc = 0.0f;
+    for (int o = 0; o < out_dim; ++o) acc = fmaf(dout[(int64_t)b * out_dim + o], w[(int64_t)o * in_dim + k], acc);
+    if (act_in) {
+        const float u = x[i];
+        const float s = 1.0f / (1.0f + expf(-u));
+        acc *= s * (1.0f + u * (1.0f - s));
+    }
+    dx[i] = accumulate ? dx[i] + acc : acc;
+}
+
+extern "C" int rho_linear_bwd(const float* dout, const float* x, const float* w, float* dw, float* db, float* dx, int64_t batch,
+                              int64_t in_dim, int64_t out_dim, int act_in, int acc_params, int acc_dx, void* stream) {
+    if (!dout || !x || !w || batch <= 0 || in_dim <= 0 || out_dim <= 0) return RHO_E_ARG;
+    if (dw) {
+        hipLaunchKernelGGL(k_linear_bwd_w, dim3((unsigned)((out_dim * in_dim + 255) / 256)), dim3(256), 0, as_stream(stream), dout, x, dw,
+                           db, (int)batch, (int)in_dim, (int)out_dim, act_in, acc_params);
+    }
+    if (dx) {
+        hipLaunchKernelGGL(k_linear_bwd_x, dim3((unsigned)((batch * in_dim + 255) / 256)), dim3(256), 0, as_stream(stream), dout, w, x, dx,
+                           (int)batch, (int)in_dim, (int)out_dim, act_in, acc_dx);
+    }
+    RHO_LAUNCH_CHECK();
+    return 0;
+}

@@ -175,3 +175,298 @@ extern "C" int rho_gn_finalize(const float* partials, int64_t n, int64_t c, int6
     RHO_LAUNCH_CHECK();
     return 0;
 }
+
+// ================================================================================================
+// Backward of  act( GroupNorm(x) * (1 + scale) + shift )  (act = SiLU or identity), recomputing the
+// forward from x, the saved statistics and the folded affine (a, b):
+//     u = a*x + b,  gq = g * act'(u),  xhat = (x - mean) * rstd,  gamma' = gamma * (1 + scale)
+//     dx = rstd * (gamma' * gq - mean_grp(gamma' * gq) - xhat * mean_grp(gamma' * gq * xhat))
+// Per-(n, c) sums R1 = sum_pos gq and R2 = sum_pos gq*xhat (pass 1, same partial layout as the
+// forward statistics) give every parameter / FiLM gradient and the group means, so pass 2 is a pure
+// elementwise   dx = A[n,c]*gq + P[n,grp] + Q[n,grp]*x .
+__device__ __forceinline__ float dsilu_f(float u) {
+    const float s = 1.0f / (1.0f + __expf(-u));
+    return s * (1.0f + u * (1.0f - s));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_gn_bwd_reduce(const T* __restrict__ g, const T* __restrict__ x1, int c1,
+                                                       const T* __restrict__ x2, int c2, int64_t s, int nblk,
+                                                       const float* __restrict__ a, const float* __restrict__ b,
+                                                       const float* __restrict__ stats, int pre_silu,
+                                                       float* __restrict__ partials) {
+    __shared__ float red[256 * 17];
+    const int C = c1 + c2;
+    const int OCT = C >> 3;
+    const int ppi = 256 / OCT;
+    const int tid = threadIdx.x;
+    const int oc = tid % OCT, pl = tid / OCT;
+    const int n = blockIdx.y, blk = blockIdx.x;
+    const int64_t per = (s + nblk - 1) / nblk;
+    const int64_t p0 = (int64_t)blk * per;
+    const int64_t p1 = (p0 + per < s) ? p0 + per : s;
+    float r1[8], r2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r1[j] = r2[j] = 0.0f;
+    if (pl < ppi) {
+        const int ch = oc * 8;
+        const T* src;
+        int64_t stride;
+        if (ch < c1) {
+            src = x1 + (int64_t)n * s * c1 + ch;
+            stride = c1;
+        } else {
+            src = x2 + (int64_t)n * s * c2 + (ch - c1);
+            stride = c2;
+        }
+        const T* gp = g + (int64_t)n * s * C + ch;
+        const int cpg = C / 32;
+        float av[8], bv[8], mu[8], rs[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            av[j] = a[(int64_t)n * C + ch + j];
+            bv[j] = b[(int64_t)n * C + ch + j];
+            const int grp = (ch + j) / cpg;
+            mu[j] = stats[((int64_t)n * 32 + grp) * 2 + 0];
+            rs[j] = stats[((int64_t)n * 32 + grp) * 2 + 1];
+        }
+        for (int64_t p = p0 + pl; p < p1; p += ppi) {
+            float xv[8], gv[8];
+            load_octet<T>(src + p * stride, xv);
+            load_octet<T>(gp + p * C, gv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float gq = gv[j];
+                if (pre_silu) gq *= dsilu_f(fmaf(av[j], xv[j], bv[j]));
+                r1[j] += gq;
+                r2[j] = fmaf(gq, (xv[j] - mu[j]) * rs[j], r2[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        red[tid * 17 + j] = r1[j];
+        red[tid * 17 + 8 + j] = r2[j];
+    }
+    __syncthreads();
+    for (int item = tid; item < OCT * 16; item += 256) {
+        const int o = item >> 4, j = item & 15;
+        float acc = 0.0f;
+        for (int q = 0; q < ppi; ++q) acc += red[(q * OCT + o) * 17 + j];
+        partials[(((int64_t)n * nblk + blk) * OCT + o) * 16 + j] = acc;
+    }
+}
+
+extern "C" int rho_gn_bwd_reduce(const void* g, const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t n,
+                                 int64_t s, const float* a, const float* b, const float* stats, int pre_silu, float* partials,
+                                 void* stream) {
+    if (!g || !x1 || !a || !b || !stats || !partials || n <= 0 || s <= 0) return RHO_E_ARG;
+    if (!x2) c2 = 0;
+    const int64_t C = c1 + c2;
+    if (C % 32 != 0 || c1 % 8 != 0 || c2 % 8 != 0 || C > 2048) return RHO_E_ALIGN;
+    const int nblk = rho_gn_nblk(s);
+    dim3 grid(nblk, (unsigned)n), block(256);
+    if (dtype == RHO_BF16)
+        hipLaunchKernelGGL(k_gn_bwd_reduce<bf16_raw>, grid, block, 0, as_stream(stream), (const bf16_raw*)g, (const bf16_raw*)x1,
+                           (int)c1, (const bf16_raw*)x2, (int)c2, s, nblk, a, b, stats, pre_silu, partials);
+    else if (dtype == RHO_F32)
+        hipLaunchKernelGGL(k_gn_bwd_reduce<float>, grid, block, 0, as_stream(stream), (const float*)g, (const float*)x1, (int)c1,
+                           (const float*)x2, (int)c2, s, nblk, a, b, stats, pre_silu, partials);
+    else
+        return RHO_E_ARG;
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
+// one block per sample: totals, group sums, per-sample parameter-gradient rows and apply coefficients
+__global__ __launch_bounds__(256) void k_gn_bwd_finalize(const float* __restrict__ partials, int c, int64_t s, int nblk,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ scale, int64_t film_stride,
+                                                         const float* __restrict__ stats, float* __restrict__ dgamma_n,
+                                                         float* __restrict__ dbeta_n, float* __restrict__ dscale,
+                                                         float* __restrict__ dshift, int64_t dfilm_stride,
+                                                         float* __restrict__ cA, float* __restrict__ cP, float* __restrict__ cQ) {
+    __shared__ float r1s[2048], r2s[2048];
+    __shared__ float s1g[32], s2g[32];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int OCT = c >> 3;
+    const int cpg = c / 32;
+    for (int ch = tid; ch < c; ch += 256) {
+        const int o = ch >> 3, j = ch & 7;
+        double a1 = 0.0, a2 = 0.0;
+        for (int k = 0; k < nblk; ++k) {
+            const float* p = partials + (((int64_t)n * nblk + k) * OCT + o) * 16;
+            a1 += (double)p[j];
+            a2 += (double)p[8 + j];
+        }
+        r1s[ch] = (float)a1;
+        r2s[ch] = (float)a2;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < cpg; ++k) {
+            const int ch = tid * cpg + k;
+            const float gp = gamma[ch] * (scale ? 1.0f + scale[(int64_t)n * film_stride + ch] : 1.0f);
+            s1 += (double)gp * r1s[ch];
+            s2 += (double)gp * r2s[ch];
+        }
+        s1g[tid] = (float)s1;
+        s2g[tid] = (float)s2;
+        const float mean = stats[((int64_t)n * 32 + tid) * 2 + 0];
+        const float rstd = stats[((int64_t)n * 32 + tid) * 2 + 1];
+        const double M = (double)cpg * (double)s;
+        cP[(int64_t)n * 32 + tid] = (float)(-(double)rstd * s1 / M + (double)rstd * rstd * s2 * mean / M);
+        cQ[(int64_t)n * 32 + tid] = (float)(-(double)rstd * rstd * s2 / M);
+    }
+    __syncthreads();
+    for (int ch = tid; ch < c; ch += 256) {
+        const int grp = ch / cpg;
+        const float rstd = stats[((int64_t)n * 32 + grp) * 2 + 1];
+        const float sc = scale ? 1.0f + scale[(int64_t)n * film_stride + ch] : 1.0f;
+        cA[(int64_t)n * c + ch] = rstd * gamma[ch] * sc;
+        dgamma_n[(int64_t)n * c + ch] = r2s[ch] * sc;
+        dbeta_n[(int64_t)n * c + ch] = r1s[ch] * sc;
+        if (dscale) {
+            dscale[(int64_t)n * dfilm_stride + ch] = gamma[ch] * r2s[ch] + beta[ch] * r1s[ch];
+            dshift[(int64_t)n * dfilm_stride + ch] = r1s[ch];
+        }
+    }
+}
+
+// out[c] (+)= sum_n in[n][c]   (deterministic order)
+__global__ void k_sum_over_n(const float* __restrict__ in, float* __restrict__ out, int n, int c, int accumulate) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    float acc = 0.0f;
+    for (int k = 0; k < n; ++k) acc += in[(int64_t)k * c + ch];
+    out[ch] = accumulate ? out[ch] + acc : acc;
+}
+
+extern "C" int rho_gn_bwd_finalize(const float* partials, int64_t n, int64_t c, int64_t s, int64_t nblk, const float* gamma,
+                                   const float* beta, const float* scale, int64_t film_stride, const float* stats,
+                                   float* work_nc2, float* dgamma, float* dbeta, int accumulate, float* dscale, float* dshift,
+                                   int64_t dfilm_stride, float* cA, float* cP, float* cQ, void* stream) {
+    if (!partials || !gamma || !beta || !stats || !work_nc2 || !dgamma || !dbeta || !cA || !cP || !cQ || n <= 0 || c <= 0 ||
+        c % 32 != 0 || c > 2048 || (dscale && !dshift))
+        return RHO_E_ARG;
+    float* dg_n = work_nc2;
+    float* db_n = work_nc2 + n * c;
+    hipLaunchKernelGGL(k_gn_bwd_finalize, dim3((unsigned)n), dim3(256), 0, as_stream(stream), partials, (int)c, s, (int)nblk, gamma,
+                       beta, scale, film_stride, stats, dg_n, db_n, dscale, dshift, dfilm_stride, cA, cP, cQ);
+    RHO_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sum_over_n, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, as_stream(stream), dg_n, dgamma, (int)n,
+                       (int)c, accumulate);
+    hipLaunchKernelGGL(k_sum_over_n, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, as_stream(stream), db_n, dbeta, (int)n,
+                       (int)c, accumulate);
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+__device__ __forceinline__ void store_octet(T* p, const float (&v)[8]);
+template <>
+__device__ __forceinline__ void store_octet<bf16_raw>(bf16_raw* p, const float (&v)[8]) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                               pack_bf16x2(v[6], v[7]));
+}
+template <>
+__device__ __forceinline__ void store_octet<float>(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_gn_bwd_apply(const T* __restrict__ g, const T* __restrict__ x1, int c1,
+                                                      const T* __restrict__ x2, int c2, int64_t s,
+                                                      const float* __restrict__ a, const float* __restrict__ b, int pre_silu,
+                                                      const float* __restrict__ cA, const float* __restrict__ cP,
+                                                      const float* __restrict__ cQ, T* __restrict__ dx1, T* __restrict__ dx2,
+                                                      int acc1, int acc2) {
+    const int C = c1 + c2;
+    const int OCT = C >> 3;
+    const int cpg = C / 32;
+    const int n = blockIdx.y;
+    const int64_t total = s * OCT;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / OCT;
+        const int oc = (int)(i - p * OCT);
+        const int ch = oc * 8;
+        const bool first = ch < c1;
+        const T* xs = first ? x1 + ((int64_t)n * s + p) * c1 + ch : x2 + ((int64_t)n * s + p) * c2 + (ch - c1);
+        T* dst = first ? dx1 + ((int64_t)n * s + p) * c1 + ch : dx2 + ((int64_t)n * s + p) * c2 + (ch - c1);
+        const int accf = first ? acc1 : acc2;
+        float xv[8], gv[8], ov[8];
+        load_octet<T>(xs, xv);
+        load_octet<T>(g + ((int64_t)n * s + p) * C + ch, gv);
+        if (accf) load_octet<T>(dst, ov);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t nc = (int64_t)n * C + ch + j;
+            float gq = gv[j];
+            if (pre_silu) gq *= dsilu_f(fmaf(a[nc], xv[j], b[nc]));
+            const int grp = (ch + j) / cpg;
+            float r = fmaf(cA[nc], gq, fmaf(cQ[(int64_t)n * 32 + grp], xv[j], cP[(int64_t)n * 32 + grp]));
+            if (accf) r += ov[j];
+            ov[j] = r;
+        }
+        store_octet<T>(dst, ov);
+    }
+}
+
+extern "C" int rho_gn_bwd_apply(const void* g, const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t n,
+                                int64_t s, const float* a, const float* b, int pre_silu, const float* cA, const float* cP,
+                                const float* cQ, void* dx1, void* dx2, int acc1, int acc2, void* stream) {
+    if (!g || !x1 || !a || !b || !cA || !cP || !cQ || !dx1 || n <= 0 || s <= 0) return RHO_E_ARG;
+    if (!x2) c2 = 0;
+    if (c2 > 0 && !dx2) return RHO_E_ARG;
+    const int64_t C = c1 + c2;
+    if (C % 32 != 0 || c1 % 8 != 0 || c2 % 8 != 0) return RHO_E_ALIGN;
+    int64_t gx = (s * (C / 8) + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    dim3 grid((unsigned)gx, (unsigned)n), block(256);
+    if (dtype == RHO_BF16)
+        hipLaunchKernelGGL(k_gn_bwd_apply<bf16_raw>, grid, block, 0, as_stream(stream), (const bf16_raw*)g, (const bf16_raw*)x1,
+                           (int)c1, (const bf16_raw*)x2, (int)c2, s, a, b, pre_silu, cA, cP, cQ, (bf16_raw*)dx1, (bf16_raw*)dx2, acc1,
+                           acc2);
+    else if (dtype == RHO_F32)
+        hipLaunchKernelGGL(k_gn_bwd_apply<float>, grid, block, 0, as_stream(stream), (const float*)g, (const float*)x1, (int)c1,
+                           (const float*)x2, (int)c2, s, a, b, pre_silu, cA, cP, cQ, (float*)dx1, (float*)dx2, acc1, acc2);
+    else
+        return RHO_E_ARG;
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Channel sums of a channels-last tensor (bias gradients, additive-embedding gradients):
+// finalisation of rho_gn_partial's first 8 lanes.   out_nc[n][c] = sum_pos x ;  out_c[c] (+)= sum_n out_nc
+__global__ __launch_bounds__(256) void k_chan_sum_finalize(const float* __restrict__ partials, int c, int nblk,
+                                                           float* __restrict__ out_nc, int64_t nc_stride, int acc_nc) {
+    const int n = blockIdx.x;
+    const int OCT = c >> 3;
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+        const int o = ch >> 3, j = ch & 7;
+        double acc = 0.0;
+        for (int k = 0; k < nblk; ++k) acc += (double)partials[(((int64_t)n * nblk + k) * OCT + o) * 16 + j];
+        float* dst = out_nc + (int64_t)n * nc_stride + ch;
+        *dst = acc_nc ? *dst + (float)acc : (float)acc;
+    }
+}
+
+extern "C" int rho_chan_sum(const void* x, int dtype, int64_t n, int64_t s, int64_t c, float* partials, float* out_nc,
+                            int64_t nc_stride, int acc_nc, float* out_c, int acc_c, void* stream) {
+    if (!x || !partials || !out_nc || n <= 0 || s <= 0 || c <= 0 || c % 32 != 0) return RHO_E_ARG;
+    int rc = rho_gn_partial(x, c, nullptr, 0, dtype, n, s, partials, stream);
+    if (rc != 0) return rc;
+    const int nblk = rho_gn_nblk(s);
+    hipLaunchKernelGGL(k_chan_sum_finalize, dim3((unsigned)n), dim3(256), 0, as_stream(stream), partials, (int)c, nblk, out_nc,
+                       nc_stride > 0 ? nc_stride : c, acc_nc);
+    if (out_c) {
+        if (nc_stride > 0 && nc_stride != c) return RHO_E_ARG;
+        hipLaunchKernelGGL(k_sum_over_n, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, as_stream(stream), out_nc, out_c, (int)n,
+                           (int)c, acc_c);
+    }
+    RHO_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,375 @@
+// Weight gradient of the n-D convolution:  dW[tap][co][ci] = sum_{n,pos} dY[n,pos,co] * Xact[n,pos (+) tap,ci]
+// (autograd of conv_nd, rho_diffusion/layers.py:77-88; Xact = SiLU(GroupNorm*FiLM(x)) is RECOMPUTED
+// in the loader from the saved pre-norm activation and the folded affine, never stored).
+//
+// Same LDS-halo organisation as the forward kernel, turned into a reduction over positions:
+//   * a workgroup owns one (64-cout x 32-cin) weight tile for ALL taps and walks a slab of 256-position
+//     output tiles; per tile it stages the input halo chunk (with the prologue) and the dY tile once,
+//   * the taps are dealt to the four waves (7+7+7+6 of 27), so the whole 27x64x32 fp32 accumulator
+//     (221 KB) lives in registers (224 per lane) across the slab and is flushed with fp32 atomics once
+//     per workgroup: 2 x 128-byte contiguous segments per wave instruction (MI355X_MICROARCH, float atomics),
+//   * the contraction index is the POSITION, but both operands are channels-last, so the MFMA
+//     fragments (8 consecutive k per lane) are produced by gfx950's transposing LDS read
+//     ds_read_b64_tr_b16 straight from the row-major tiles - no transposed copies.
+// The exact-f32 variant (v_mfma_f32_32x32x2_f32) needs one k per lane, i.e. plain ds_read_b32.
+#include "conv_common.h"
+
+#define DY_PITCH 144   // 128 B of dY channels (64 bf16 / 32 f32) + 16 B pad
+
+struct WgradK {
+    const char* x1;
+    const char* x2;
+    const float* pre_a;
+    const float* pre_b;
+    const char* dy;
+    float* dw;
+    int c1, c2, cin;
+    int dyw;            // row width (elements) of dY
+    int coutp;          // rows of the dw buffer
+    int D, H, W, Do, Ho, Wo;
+    long long S_in;
+    int sh, sw, pre_silu;
+    int TD, TH, TW, ID, IH, IW, NP;
+    int lgTW, lgTH;
+    int tiles_d, tiles_h, tiles_w, n_batch;
+    int tiles_total, tiles_per_block;
+};
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+// 32(row/col) x 16(k) bf16 MFMA operand out of a row-major [k][channel] LDS tile: lane (col = l&31,
+// half = l>>5) gets k = 8*half + {0..7}.  Per 16-lane group the transposing read takes row addresses
+// from lanes 4q+p (row q, columns 4p..4p+3) and returns column i of the 4 rows to lane i.
+// r0 / r1: byte offsets of this lane's k-rows (4t + q, t = 0/1) incl. the column offset.
+__device__ __forceinline__ uint4 tr_frag(const char* lds, int r0, int r1) {
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(lds + r0));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(lds + r1));
+    uint4 f;
+    f.x = (uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+    f.y = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+    f.z = (uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+    f.w = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+    return f;
+}
+
+template <typename T, int KD, int KH, int KW, int MAXP>
+__global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CK = ET<T>::CK;
+    constexpr int PE = ET<T>::PE;
+    constexpr int NT = KD * KH * KW;
+    constexpr bool TAPSPLIT = NT >= 9;               // taps dealt to waves; else positions dealt to waves
+    constexpr int TPW = TAPSPLIT ? (NT + 3) / 4 : NT;  // taps per wave
+    constexpr int COT = 128 / (int)sizeof(T);        // cout tile: 64 bf16 / 32 f32
+    constexpr int MT = COT / 32;
+    constexpr bool IS_BF16 = sizeof(T) == 2;
+
+    char* const halo = smem;
+    char* const dyt = smem + (size_t)p.NP * PITCH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int piece = tid & 3;
+    const int co0 = blockIdx.y * COT;
+    const int c = blockIdx.z * CK;        // input-channel chunk of this workgroup
+    const char* src;
+    int cs, csrc;
+    if (c < p.c1) { src = p.x1; cs = p.c1; csrc = c; } else { src = p.x2; cs = p.c2; csrc = c - p.c1; }
+
+    // halo slot -> (id, ih, iw), fixed for every tile
+    int sdec[MAXP];
+    {
+        const int ihw = p.IH * p.IW;
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int hp = (tid >> 2) + 64 * i;
+            int v = -1;
+            if (hp < p.NP) {
+                const int id = hp / ihw;
+                const int r = hp - id * ihw;
+                const int ih = r / p.IW;
+                v = (id << 20) | (ih << 10) | (r - ih * p.IW);
+            }
+            sdec[i] = v;
+        }
+    }
+
+    // taps of this wave
+    int tap_of[TPW], tapoff[TPW];
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+        const int tap = TAPSPLIT ? wave + 4 * ti : ti;
+        tap_of[ti] = tap;
+        const int kd = tap / (KH * KW), kh = (tap / KW) % KH, kw = tap % KW;
+        tapoff[ti] = ((kd * p.IH + kh) * p.IW + kw) * PITCH;
+    }
+
+    f32x16_t acc[TPW][MT];
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti)
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ti][mi][r] = 0.0f;
+
+    // lane geometry of the transposing reads
+    const int grp = lane >> 4, li = lane & 15, q = li >> 2, pq = li & 3;
+    const int colb = 16 * (grp & 1) + 4 * pq;          // channel of this lane's 8-byte address within a 32-wide tile
+
+    const int tile0 = blockIdx.x * p.tiles_per_block;
+    const int tile1 = min(tile0 + p.tiles_per_block, p.tiles_total);
+    for (int tl = tile0; tl < tile1; ++tl) {
+        int t = tl;
+        const int tw_i = t % p.tiles_w; t /= p.tiles_w;
+        const int th_i = t % p.tiles_h; t /= p.tiles_h;
+        const int td_i = t % p.tiles_d;
+        const int n = t / p.tiles_d;
+        const int od0 = td_i * p.TD, oh0 = th_i * p.TH, ow0 = tw_i * p.TW;
+        const int gd_base = od0 - (KD / 2), gh_base = oh0 * p.sh - (KH / 2), gw_base = ow0 * p.sw - (KW / 2);
+
+        __syncthreads();   // previous tile's fragments consumed
+        // ---- input halo chunk (prologue applied, zero padding after the activation)
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            if (sdec[i] >= 0) {
+                const int id = sdec[i] >> 20, ih = (sdec[i] >> 10) & 1023, iw = sdec[i] & 1023;
+                const int gd = gd_base + id, gh = gh_base + ih, gw = gw_base + iw;
+                uint4 u = make_uint4(0u, 0u, 0u, 0u);
+                if (gd >= 0 && gd < p.D && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W) {
+                    const int pos = ((n * p.D + gd) * p.H + gh) * p.W + gw;
+                    u = *reinterpret_cast<const uint4*>(src + ((size_t)pos * cs + csrc) * sizeof(T) + piece * 16);
+                    if (p.pre_a != nullptr) {
+                        const int smp = (KD == 3) ? n : (int)((unsigned)pos / (unsigned)p.S_in);
+                        const size_t co = (size_t)smp * p.cin + c + piece * PE;
+                        u = apply_pre<T>(u, p.pre_a + co, p.pre_b + co, p.pre_silu);
+                    }
+                }
+                const int hp = (tid >> 2) + 64 * i;
+                *reinterpret_cast<uint4*>(halo + hp * PITCH + piece * 16) = u;
+            }
+        }
+        // ---- dY tile: 256 positions x 128 bytes
+        {
+            const int dpiece = tid & 7;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = (tid >> 3) + 32 * i;
+                const int pw = row & (p.TW - 1), ph = (row >> p.lgTW) & (p.TH - 1), pd = row >> (p.lgTW + p.lgTH);
+                const int od = od0 + pd, oh = oh0 + ph, ow = ow0 + pw;
+                uint4 u = make_uint4(0u, 0u, 0u, 0u);
+                const int ch = co0 + dpiece * PE;
+                if (od < p.Do && oh < p.Ho && ow < p.Wo && ch < p.dyw) {
+                    const size_t L = (((size_t)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
+                    u = *reinterpret_cast<const uint4*>(p.dy + (L * p.dyw + ch) * sizeof(T));
+                }
+                *reinterpret_cast<uint4*>(dyt + row * DY_PITCH + dpiece * 16) = u;
+            }
+        }
+        __syncthreads();
+
+        // ---- reduce this tile's positions
+        if constexpr (IS_BF16) {
+            const int ks0 = TAPSPLIT ? 0 : wave * 4;
+            const int ks1 = TAPSPLIT ? 16 : wave * 4 + 4;
+            for (int ks = ks0; ks < ks1; ++ks) {
+                // k rows of this lane: position index 16*ks + 8*half' + 4*t + q with half' = grp>>1
+                int xr[2], ar[2];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int pp = 16 * ks + 8 * (grp >> 1) + 4 * tt + q;
+                    const int pw = pp & (p.TW - 1), ph = (pp >> p.lgTW) & (p.TH - 1), pd = pp >> (p.lgTW + p.lgTH);
+                    xr[tt] = ((pd * p.IH + ph * p.sh) * p.IW + pw * p.sw) * PITCH + colb * 2;
+                    ar[tt] = pp * DY_PITCH + colb * 2;
+                }
+                uint4 a[MT];
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) a[mi] = tr_frag(dyt, ar[0] + mi * 64, ar[1] + mi * 64);
+#pragma unroll
+                for (int ti = 0; ti < TPW; ++ti) {
+                    if (tap_of[ti] < NT) {
+                        const uint4 b = tr_frag(halo, xr[0] + tapoff[ti], xr[1] + tapoff[ti]);
+#pragma unroll
+                        for (int mi = 0; mi < MT; ++mi) mma_step<T>(a[mi], b, acc[ti][mi]);
+                    }
+                }
+            }
+        } else {
+            // exact f32: k = position pair (2*kk + half); lanes with ci >= 16 contribute zeros
+            const int kk0 = TAPSPLIT ? 0 : wave * 32;
+            const int kk1 = TAPSPLIT ? 128 : wave * 32 + 32;
+            const int col = lane & 31;
+            for (int kk = kk0; kk < kk1; ++kk) {
+                const int pp = 2 * kk + half;
+                const int pw = pp & (p.TW - 1), ph = (pp >> p.lgTW) & (p.TH - 1), pd = pp >> (p.lgTW + p.lgTH);
+                const float av = *reinterpret_cast<const float*>(dyt + pp * DY_PITCH + col * 4);
+                const int xrow = ((pd * p.IH + ph * p.sh) * p.IW + pw * p.sw) * PITCH + (col & 15) * 4;
+#pragma unroll
+                for (int ti = 0; ti < TPW; ++ti) {
+                    if (tap_of[ti] < NT) {
+                        float bv = *reinterpret_cast<const float*>(halo + xrow + tapoff[ti]);
+                        bv = (col < 16) ? bv : 0.0f;
+                        acc[ti][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[ti][0], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- flush: lane holds ci = c + (lane&31), rows co0 + 32*mi + (r&3) + 8*(r>>2) + 4*half
+    const int ci = c + (lane & 31);
+    const bool ci_ok = IS_BF16 ? true : ((lane & 31) < 16);
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+        if (tap_of[ti] < NT && ci_ok) {
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (co < p.coutp) atomicAdd(p.dw + ((size_t)tap_of[ti] * p.coutp + co) * p.cin + ci, acc[ti][mi][r]);
+                }
+        }
+    }
+}
+
+namespace {
+using namespace rho_conv;
+
+template <typename T, int KD, int KH, int KW>
+int launch_wgrad(const WgradK& k, int maxp, dim3 grid, size_t lds, hipStream_t st) {
+    if (maxp <= 10) {
+        auto fn = k_wgrad<T, KD, KH, KW, 10>;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, k);
+    } else {
+        auto fn = k_wgrad<T, KD, KH, KW, 28>;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, k);
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+template <typename T>
+int launch_wgrad_taps(const rho_conv_desc& d, const WgradK& k, int maxp, dim3 grid, size_t lds, hipStream_t st) {
+    if (d.kd == 3 && d.kh == 3 && d.kw == 3) return launch_wgrad<T, 3, 3, 3>(k, maxp, grid, lds, st);
+    if (d.kd == 1 && d.kh == 3 && d.kw == 3) return launch_wgrad<T, 1, 3, 3>(k, maxp, grid, lds, st);
+    if (d.kd == 1 && d.kh == 1 && d.kw == 3) return launch_wgrad<T, 1, 1, 3>(k, maxp, grid, lds, st);
+    if (d.kd == 1 && d.kh == 1 && d.kw == 1) return launch_wgrad<T, 1, 1, 1>(k, maxp, grid, lds, st);
+    return RHO_E_ARG;
+}
+
+inline int ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+}  // namespace
+
+// desc describes the FORWARD convolution (x1/x2, prologue, geometry); dy is its output gradient
+// (channels-last, row width dy_width >= cout, extra channels must be zero); dw is an fp32 buffer
+// [taps][coutp][c1+c2] that this call ACCUMULATES into (zero it first).  up_h/up_w are not supported:
+// materialise the upsampled input (rho_upsample2x) and pass it as x1.
+extern "C" int rho_conv_nd_wgrad(const rho_conv_desc* dp, const void* dy, int64_t dy_width, float* dw, void* stream) {
+    if (!dp || !dy || !dw) return RHO_E_ARG;
+    const rho_conv_desc& d = *dp;
+    if (!d.x1) return RHO_E_ARG;
+    if (d.dtype != RHO_F32 && d.dtype != RHO_BF16) return RHO_E_ARG;
+    if (d.up_h || d.up_w || d.zs_h || d.zs_w) return RHO_E_ARG;
+    const int CK = d.dtype == RHO_BF16 ? 32 : 16;
+    const int PE = d.dtype == RHO_BF16 ? 8 : 4;
+    const int COT = d.dtype == RHO_BF16 ? 64 : 32;
+    const int c2 = d.x2 ? d.c2 : 0;
+    const int cin = d.c1 + c2;
+    if (d.c1 <= 0 || d.c1 % CK || c2 % CK) return RHO_E_ALIGN;
+    if (dy_width <= 0 || dy_width % PE || d.coutp <= 0 || d.coutp % 32) return RHO_E_ALIGN;
+    if ((d.sh != 1 && d.sh != 2) || (d.sw != 1 && d.sw != 2)) return RHO_E_ARG;
+    if (d.pre_a && !d.pre_b) return RHO_E_ARG;
+
+    const int ho = (d.h + 2 * (d.kh / 2) - d.kh) / d.sh + 1;
+    const int wo = (d.w_ + 2 * (d.kw / 2) - d.kw) / d.sw + 1;
+    WgradK k{};
+    int nb = d.n;
+    if (d.kd == 1 && d.kh == 1 && d.kw == 1) {
+        if (d.sh != 1 || d.sw != 1) return RHO_E_ARG;
+        k.D = 1; k.H = 1; k.W = d.n * d.d * d.h * d.w_;
+        k.Do = 1; k.Ho = 1; k.Wo = k.W;
+        nb = 1;
+    } else if (d.kd == 1) {
+        k.D = d.n * d.d; k.H = d.h; k.W = d.w_;
+        k.Do = k.D; k.Ho = ho; k.Wo = wo;
+        nb = 1;
+    } else {
+        k.D = d.d; k.H = d.h; k.W = d.w_;
+        k.Do = d.d; k.Ho = ho; k.Wo = wo;
+    }
+    if ((long long)d.n * d.d * d.h * d.w_ >= (1LL << 31)) return RHO_E_SHAPE;
+    k.S_in = (long long)d.d * d.h * d.w_;
+
+    const size_t lds_cap = 160 * 1024;
+    int np_cap = (int)((lds_cap - 256 * DY_PITCH) / PITCH);
+    if (np_cap > 28 * 64) np_cap = 28 * 64;
+    TileChoice t = choose_tile(d, k.D, k.Do, k.Ho, k.Wo, 640);
+    if (!t.ok) t = choose_tile(d, k.D, k.Do, k.Ho, k.Wo, np_cap);
+    if (!t.ok) return RHO_E_SHAPE;
+
+    k.x1 = (const char*)d.x1; k.x2 = (const char*)d.x2; k.pre_a = d.pre_a; k.pre_b = d.pre_b;
+    k.dy = (const char*)dy; k.dw = dw;
+    k.c1 = d.c1; k.c2 = c2; k.cin = cin; k.dyw = (int)dy_width; k.coutp = d.coutp;
+    k.sh = d.sh; k.sw = d.sw; k.pre_silu = d.pre_silu;
+    k.TD = t.TD; k.TH = t.TH; k.TW = t.TW; k.ID = t.ID; k.IH = t.IH; k.IW = t.IW; k.NP = t.NP;
+    k.lgTW = ilog2(t.TW); k.lgTH = ilog2(t.TH);
+    k.tiles_d = cdiv(k.Do, t.TD); k.tiles_h = cdiv(k.Ho, t.TH); k.tiles_w = cdiv(k.Wo, t.TW);
+    k.n_batch = nb;
+    const long long tiles = (long long)nb * k.tiles_d * k.tiles_h * k.tiles_w;
+    if (tiles > 0x7FFFFFFFLL) return RHO_E_SHAPE;
+    k.tiles_total = (int)tiles;
+    // enough workgroups to fill 256 CUs, long enough slabs to amortise the 27x64x32 fp32 flush
+    const int pairs = cdiv(d.coutp, COT) * (cin / CK);
+    int splits = cdiv(1024, pairs);
+    if (splits < 1) splits = 1;
+    if (splits > k.tiles_total) splits = k.tiles_total;
+    k.tiles_per_block = cdiv(k.tiles_total, splits);
+    splits = cdiv(k.tiles_total, k.tiles_per_block);
+    if (cdiv(d.coutp, COT) > 65535 || cin / CK > 65535) return RHO_E_SHAPE;
+    dim3 grid((unsigned)splits, (unsigned)cdiv(d.coutp, COT), (unsigned)(cin / CK));
+    const size_t lds = (size_t)t.NP * PITCH + 256 * DY_PITCH;
+    const int maxp = cdiv(t.NP, 64);
+    hipStream_t st = as_stream(stream);
+    if (d.dtype == RHO_BF16) return launch_wgrad_taps<bf16_raw>(d, k, maxp, grid, lds, st);
+    return launch_wgrad_taps<float>(d, k, maxp, grid, lds, st);
+}
+
+// fp32 [taps][coutp][cin_buf] accumulation buffer -> parameter-gradient layout [cout][cin][taps] (fp32),
+// undoing the qkv row permutation if any; accumulate = 1 adds to the existing .grad.
+__global__ __launch_bounds__(256) void k_wgrad_finalize(const float* __restrict__ dw, float* __restrict__ grad, int64_t cout,
+                                                        int64_t cin, int64_t taps, int64_t coutp, int64_t cinb,
+                                                        const int32_t* __restrict__ row_src, int accumulate) {
+    const int64_t total = cout * cin * taps;   // over buffer rows r (permuted order), written to original rows
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t tap = i % taps;
+        const int64_t ci = (i / taps) % cin;
+        const int64_t r = i / (taps * cin);
+        const int64_t dst_row = row_src ? (int64_t)row_src[r] : r;
+        if (dst_row < 0 || dst_row >= cout) continue;
+        const float v = dw[(tap * coutp + r) * cinb + ci];
+        float* g = grad + (dst_row * cin + ci) * taps + tap;
+        *g = accumulate ? *g + v : v;
+    }
+}
+
+extern "C" int rho_wgrad_finalize(const float* dw, float* grad, int64_t cout, int64_t cin, int64_t taps, int64_t coutp,
+                                  int64_t cin_buf, const int32_t* row_src, int accumulate, void* stream) {
+    if (!dw || !grad || cout <= 0 || cin <= 0 || taps <= 0 || coutp < cout || cin_buf < cin) return RHO_E_ARG;
+    int64_t g = (cout * cin * taps + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_wgrad_finalize, dim3((unsigned)g), dim3(256), 0, as_stream(stream), dw, grad, cout, cin, taps, coutp, cin_buf,
+                       row_src, accumulate);
+    RHO_LAUNCH_CHECK();
+    return 0;
+}

@@ -172,7 +172,8 @@ def gn_coeffs(x1: Tensor, x2: Optional[Tensor], gamma: Tensor, beta: Tensor, sca
 def make_conv_desc(x1: Tensor, x2: Optional[Tensor], w: Tensor, bias: Tensor, *, kernel: Tuple[int, int, int],
                    cout: int, split: int, y: Optional[Tensor], y2: Optional[Tensor], stride_hw=(1, 1), up_hw=(0, 0),
                    pre_a: Optional[Tensor] = None, pre_b: Optional[Tensor] = None, pre_silu: bool = False,
-                   res: Optional[Tensor] = None, res_add: Optional[Tensor] = None, res_add_stride: int = 0) -> ConvDesc:
+                   res: Optional[Tensor] = None, res_add: Optional[Tensor] = None, res_add_stride: int = 0,
+                   y2_cl: bool = False, res2: Optional[Tensor] = None, zs_hw=(0, 0), out_hw=(0, 0)) -> ConvDesc:
     N, D, H, W, c1 = x1.shape
     d = ConvDesc()
     d.x1, d.x2 = ptr(x1), ptr(x2)
@@ -191,6 +192,10 @@ def make_conv_desc(x1: Tensor, x2: Optional[Tensor], w: Tensor, bias: Tensor, *,
     d.up_h, d.up_w = up_hw
     d.pre_silu = int(pre_silu)
     d.res_add_stride = res_add_stride
+    d.y2_cl = int(y2_cl)
+    d.res2 = ptr(res2)
+    d.zs_h, d.zs_w = int(zs_hw[0]), int(zs_hw[1])
+    d.out_h, d.out_w = int(out_hw[0]), int(out_hw[1])
     if w.shape[2] != d.c1 + d.c2:
         raise RhoHipError(f"conv: prepared weight has {w.shape[2]} input channels, inputs provide {d.c1 + d.c2}")
     return d
@@ -225,12 +230,115 @@ def conv(x1: Tensor, x2: Optional[Tensor], w: Tensor, bias: Tensor, *, kernel, c
 
 
 # ----------------------------------------------------------------------------- attention
-def attention(qk: Tensor, vt: Tensor, heads: int, out: Optional[Tensor] = None) -> Tensor:
-    """qk channels-last [B, T, 2C], vt channel-major [B, C, T] -> channels-last [B, T, C]."""
+def attention(qk: Tensor, vt: Tensor, heads: int, out: Optional[Tensor] = None, lse: Optional[Tensor] = None) -> Tensor:
+    """qk channels-last [B, T, 2C], vt channel-major [B, C, T] -> channels-last [B, T, C].
+    lse (optional float32 [B, heads, T]) receives the per-query log-sum-exp for the backward."""
     B, T, C2 = qk.shape
     Cc = C2 // 2
     ch = Cc // heads
     out = torch.empty(B, T, Cc, dtype=qk.dtype, device=qk.device) if out is None else out
-    check(hip.lib().rho_attention_fwd(ptr(qk), ptr(vt), ptr(out), dtype_code(qk.dtype), B, T, heads, ch, stream()),
+    check(hip.lib().rho_attention_fwd(ptr(qk), ptr(vt), ptr(out), ptr(lse), dtype_code(qk.dtype), B, T, heads, ch, stream()),
           "rho_attention_fwd")
     return out
+
+
+# ============================================================================= backward ops
+def prep_conv_weight_dgrad(w: Tensor, dtype: torch.dtype, col_src: Optional[Tensor] = None,
+                           out: Optional[Tensor] = None) -> Tensor:
+    """PyTorch conv weight [Cout, Cin, *k] -> dgrad weights [taps, ceil32(Cin), ceilCK(Cout)] (flipped, transposed)."""
+    _f32c(w, "w")
+    cout, cin = w.shape[0], w.shape[1]
+    taps = int(math.prod(w.shape[2:])) if w.dim() > 2 else 1
+    ck = elem_chunk(dtype)
+    rowsp = ((cin + 31) // 32) * 32
+    colsp = ((cout + ck - 1) // ck) * ck
+    out = torch.empty(taps, rowsp, colsp, dtype=dtype, device=w.device) if out is None else out
+    check(hip.lib().rho_prep_conv_weight_dgrad(ptr(w), ptr(out), dtype_code(dtype), cout, cin, taps, rowsp, colsp, ptr(col_src),
+                                               stream()), "rho_prep_conv_weight_dgrad")
+    return out
+
+
+def conv_wgrad(desc: ConvDesc, dy: Tensor, dw: Tensor) -> None:
+    """Accumulate the weight gradient of the forward conv `desc` into the fp32 buffer dw [taps, coutp, cin]."""
+    check(hip.lib().rho_conv_nd_wgrad(C.byref(desc), ptr(dy), dy.shape[-1], ptr(dw), stream()), "rho_conv_nd_wgrad")
+
+
+def wgrad_finalize(dw: Tensor, grad: Tensor, row_src: Optional[Tensor] = None, accumulate: bool = False) -> None:
+    cout, cin = grad.shape[0], grad.shape[1]
+    taps = grad.numel() // (cout * cin)
+    check(hip.lib().rho_wgrad_finalize(ptr(dw), ptr(grad), cout, cin, taps, dw.shape[1], dw.shape[2], ptr(row_src), int(accumulate),
+                                       stream()), "rho_wgrad_finalize")
+
+
+def gn_bwd(g: Tensor, x1: Tensor, x2: Optional[Tensor], a: Tensor, b: Tensor, stats: Tensor, gamma: Tensor, beta: Tensor,
+           pre_silu: bool, dx1: Tensor, dx2: Optional[Tensor], dgamma: Tensor, dbeta: Tensor, *, scale=None, film_stride=0,
+           dscale=None, dshift=None, dfilm_stride=0, acc_params=False, acc1=False, acc2=False, ws=None):
+    """Backward of act(GN(x)*(1+scale)+shift); scale/dscale/dshift may be raw pointers (ints) or tensors."""
+    N = x1.shape[0]
+    c1 = x1.shape[-1]
+    c2 = x2.shape[-1] if x2 is not None else 0
+    Cc = c1 + c2
+    S = x1.numel() // (N * c1)
+    nblk = gn_nblk(S)
+    dev = x1.device
+    if ws is None:
+        ws = dict(part=torch.empty(N * nblk * (Cc // 8) * 16, dtype=torch.float32, device=dev),
+                  work=torch.empty(2 * N * Cc, dtype=torch.float32, device=dev),
+                  cA=torch.empty(N, Cc, dtype=torch.float32, device=dev), cP=torch.empty(N, 32, dtype=torch.float32, device=dev),
+                  cQ=torch.empty(N, 32, dtype=torch.float32, device=dev))
+    L = hip.lib()
+    dt = dtype_code(x1.dtype)
+    p = lambda t: t if isinstance(t, int) or t is None else t.data_ptr()  # noqa: E731
+    check(L.rho_gn_bwd_reduce(ptr(g), ptr(x1), c1, ptr(x2), c2, dt, N, S, ptr(a), ptr(b), ptr(stats), int(pre_silu), ptr(ws["part"]),
+                              stream()), "rho_gn_bwd_reduce")
+    check(L.rho_gn_bwd_finalize(ptr(ws["part"]), N, Cc, S, nblk, ptr(gamma), ptr(beta), p(scale), film_stride, ptr(stats),
+                                ptr(ws["work"]), ptr(dgamma), ptr(dbeta), int(acc_params), p(dscale), p(dshift), dfilm_stride,
+                                ptr(ws["cA"]), ptr(ws["cP"]), ptr(ws["cQ"]), stream()), "rho_gn_bwd_finalize")
+    check(L.rho_gn_bwd_apply(ptr(g), ptr(x1), c1, ptr(x2), c2, dt, N, S, ptr(a), ptr(b), int(pre_silu), ptr(ws["cA"]), ptr(ws["cP"]),
+                             ptr(ws["cQ"]), ptr(dx1), ptr(dx2), int(acc1), int(acc2), stream()), "rho_gn_bwd_apply")
+
+
+def chan_sum(x: Tensor, out_nc: Tensor, out_c: Optional[Tensor] = None, nc_stride: int = 0, acc_nc=False, acc_c=False,
+             partials: Optional[Tensor] = None) -> None:
+    N, Cc = x.shape[0], x.shape[-1]
+    S = x.numel() // (N * Cc)
+    nblk = gn_nblk(S)
+    partials = torch.empty(N * nblk * (Cc // 8) * 16, dtype=torch.float32, device=x.device) if partials is None else partials
+    onc = out_nc if isinstance(out_nc, int) else out_nc.data_ptr()
+    check(hip.lib().rho_chan_sum(ptr(x), dtype_code(x.dtype), N, S, Cc, ptr(partials), onc, nc_stride, int(acc_nc), ptr(out_c),
+                                 int(acc_c), stream()), "rho_chan_sum")
+
+
+def upsample2x(x: Tensor, up_hw, out: Optional[Tensor] = None) -> Tensor:
+    N, D, H, W, Cc = x.shape
+    out = torch.empty(N, D, H * (2 if up_hw[0] else 1), W * (2 if up_hw[1] else 1), Cc, dtype=x.dtype, device=x.device) if out is None else out
+    check(hip.lib().rho_upsample2x(ptr(x), ptr(out), dtype_code(x.dtype), N * D, H, W, Cc, int(up_hw[0]), int(up_hw[1]), stream()),
+          "rho_upsample2x")
+    return out
+
+
+def pool2x_sum(dy: Tensor, dx: Tensor, up_hw, accumulate: bool = False) -> Tensor:
+    N, D, H, W, Cc = dx.shape
+    check(hip.lib().rho_pool2x_sum(ptr(dy), ptr(dx), dtype_code(dx.dtype), N * D, H, W, Cc, int(up_hw[0]), int(up_hw[1]),
+                                   int(accumulate), stream()), "rho_pool2x_sum")
+    return dx
+
+
+def linear_bwd(dout: Tensor, x: Tensor, w: Tensor, dw: Optional[Tensor], db: Optional[Tensor], dx: Optional[Tensor],
+               act_in: bool = False, acc_params: bool = False, acc_dx: bool = False) -> None:
+    B, K = x.shape
+    O = w.shape[0]
+    check(hip.lib().rho_linear_bwd(ptr(dout), ptr(x), ptr(w), ptr(dw), ptr(db), ptr(dx), B, K, O, int(act_in), int(acc_params),
+                                   int(acc_dx), stream()), "rho_linear_bwd")
+
+
+def attention_bwd(qk: Tensor, vt: Tensor, o: Tensor, dout: Tensor, lse: Tensor, heads: int, dqk: Optional[Tensor] = None,
+                  dv: Optional[Tensor] = None, delta_ws: Optional[Tensor] = None):
+    B, T, C2 = qk.shape
+    Cc = C2 // 2
+    dqk = torch.empty_like(qk) if dqk is None else dqk
+    dv = torch.empty(B, T, Cc, dtype=qk.dtype, device=qk.device) if dv is None else dv
+    delta_ws = torch.empty(B, heads, T, dtype=torch.float32, device=qk.device) if delta_ws is None else delta_ws
+    check(hip.lib().rho_attention_bwd(ptr(qk), ptr(vt), ptr(o), ptr(dout), ptr(lse), ptr(delta_ws), ptr(dqk), ptr(dv),
+                                      dtype_code(qk.dtype), B, T, heads, Cc // heads, stream()), "rho_attention_bwd")
+    return dqk, dv

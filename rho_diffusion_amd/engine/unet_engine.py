@@ -302,7 +302,7 @@ class _Plan:
             a, b = gn(xin, None, blk.norm)
             qk, vt = conv(xin, None, eng._conv(blk.qkv), pre=(a, b), pre_silu=False, split=2 * Cc)
             ao = buf(N, Dd, Hh, Ww, Cc)
-            args = (ptr(qk), ptr(vt), ptr(ao), hip.dtype_code(dt), N, T, blk.num_heads, Cc // blk.num_heads)
+            args = (ptr(qk), ptr(vt), ptr(ao), None, hip.dtype_code(dt), N, T, blk.num_heads, Cc // blk.num_heads)
             self.ops.append(lambda s, a=args: L.rho_attention_fwd(*a, s))
             esz = 2 if dt == torch.bfloat16 else 4
             self.info.append(dict(kind="attention", flops=4.0 * N * T * T * Cc, bytes=float(esz) * 4 * N * T * Cc))

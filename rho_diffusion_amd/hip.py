@@ -30,6 +30,8 @@ class ConvDesc(C.Structure):
         ("n", c_int32), ("d", c_int32), ("h", c_int32), ("w_", c_int32),
         ("kd", c_int32), ("kh", c_int32), ("kw", c_int32), ("sh", c_int32), ("sw", c_int32),
         ("up_h", c_int32), ("up_w", c_int32), ("pre_silu", c_int32), ("res_add_stride", c_int32),
+        ("y2_cl", c_int32), ("zs_h", c_int32), ("zs_w", c_int32), ("out_h", c_int32), ("out_w", c_int32),
+        ("res2", c_void_p),
     ]
 
 
@@ -52,7 +54,25 @@ SIGNATURES = {
     "rho_gn_finalize": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                 c_void_p, c_void_p, c_void_p, c_void_p]),
     "rho_conv_nd_fwd": (c_int, [C.POINTER(ConvDesc), c_void_p]),
-    "rho_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p]),
+    "rho_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p]),
+    # ---- backward
+    "rho_conv_nd_wgrad": (c_int, [C.POINTER(ConvDesc), c_void_p, c_int64, c_void_p, c_void_p]),
+    "rho_wgrad_finalize": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int, c_void_p]),
+    "rho_prep_conv_weight_dgrad": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    "rho_gn_bwd_reduce": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p,
+                                  c_void_p, c_int, c_void_p, c_void_p]),
+    "rho_gn_bwd_finalize": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                    c_void_p]),
+    "rho_gn_bwd_apply": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "rho_chan_sum": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p]),
+    "rho_upsample2x": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "rho_pool2x_sum": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "rho_linear_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int,
+                               c_int, c_void_p]),
+    "rho_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,
+                                  c_int64, c_int64, c_int64, c_void_p]),
 }
 
 
