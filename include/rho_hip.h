@@ -223,15 +223,25 @@ int rho_pool2x_sum(const void* dy, void* dx, int dtype, int64_t n_times_d, int64
                    int up_w, int accumulate, void* stream);
 
 /* Backward of rho_linear: dw[o,k] (+)= sum_b dout[b,o] act(x[b,k]); db[o] (+)= sum_b dout[b,o];
- * dx[b,k] (+)= act'(x[b,k]) sum_o dout[b,o] w[o,k].  dw/db/dx may be NULL. */
-int rho_linear_bwd(const float* dout, const float* x, const float* w, float* dw, float* db, float* dx, int64_t batch,
-                   int64_t in_dim, int64_t out_dim, int act_in, int acc_params, int acc_dx, void* stream);
+ * dx[b,k] (+)= act'(x[b,k]) sum_o dout[b,o] w[o,k].  dw/db/dx may be NULL; dout rows are dout_stride floats apart
+ * (0 = out_dim) so a slice of the batched FiLM gradient can be passed in place. */
+int rho_linear_bwd(const float* dout, int64_t dout_stride, const float* x, const float* w, float* dw, float* db,
+                   float* dx, int64_t batch, int64_t in_dim, int64_t out_dim, int act_in, int acc_params, int acc_dx,
+                   void* stream);
+
+/* x *= *scale_dev over n float32 elements: the upstream scalar of loss.backward() applied to d(loss)/d(pred)
+ * without a host round trip. */
+int rho_scale_by_device_scalar(float* x, const float* scale_dev, int64_t n, void* stream);
+
+/* dst += src over n elements of `dtype` (gradient accumulation where a tensor has several consumers). */
+int rho_add_inplace(void* dst, const void* src, int dtype, int64_t n, void* stream);
 
 /* Backward of rho_attention_fwd (recompute from lse).  o / dout channels-last [B,T,C]; delta_ws float32
- * [B,heads,T] scratch; outputs dqk [B,T,2C] (dq | dk) and dv [B,T,C], channels-last in `dtype`. */
+ * [B,heads,T] scratch; outputs dqk [B,T,2C] (dq | dk) and dv [B,T,C], channels-last in `dtype`, with explicit row
+ * strides in elements (0 = dense) so both can be column ranges of one [B,T,3C] buffer = the qkv projection's dY. */
 int rho_attention_bwd(const void* qk, const void* vt, const void* o, const void* dout, const float* lse,
-                      float* delta_ws, void* dqk, void* dv, int dtype, int64_t batch, int64_t t, int64_t heads,
-                      int64_t ch, void* stream);
+                      float* delta_ws, void* dqk, int64_t dqk_row_stride, void* dv, int64_t dv_row_stride, int dtype,
+                      int64_t batch, int64_t t, int64_t heads, int64_t ch, void* stream);
 
 #ifdef __cplusplus
 }

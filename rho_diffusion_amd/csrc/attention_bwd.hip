@@ -70,7 +70,7 @@ template <int CH, int KT>
 __global__ __launch_bounds__(256) void k_attn_dq(const bf16_raw* __restrict__ qk, const bf16_raw* __restrict__ vt,
                                                  const bf16_raw* __restrict__ dout, const float* __restrict__ lse,
                                                  const float* __restrict__ delta, bf16_raw* __restrict__ dqk, int T, int C,
-                                                 float scale_log2e, float scale) {
+                                                 float scale_log2e, float scale, int dqk_rs) {
     constexpr int KP = CH * 2 + 16;
     constexpr int VP = KT * 2 + 16;
     constexpr int NKK = CH / 16;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void k_attn_dq(const bf16_raw* __restrict__ qk
         }
     }
     if (qi < T) {
-        bf16_raw* op = dqk + ((size_t)b * T + qi) * row2c + (size_t)h * CH;
+        bf16_raw* op = dqk + ((size_t)b * T + qi) * dqk_rs + (size_t)h * CH;
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
@@ -190,7 +190,8 @@ template <int CH, int QT>
 __global__ __launch_bounds__(256) void k_attn_dkv(const bf16_raw* __restrict__ qk, const bf16_raw* __restrict__ vt,
                                                   const bf16_raw* __restrict__ dout, const float* __restrict__ lse,
                                                   const float* __restrict__ delta, bf16_raw* __restrict__ dqk,
-                                                  bf16_raw* __restrict__ dv, int T, int C, float scale_log2e, float scale) {
+                                                  bf16_raw* __restrict__ dv, int T, int C, float scale_log2e, float scale,
+                                                  int dqk_rs, int dv_rs) {
     constexpr int KP = CH * 2 + 16;
     constexpr int NKK = CH / 16;
     constexpr int NCT = (CH + 31) / 32;
@@ -294,8 +295,8 @@ __global__ __launch_bounds__(256) void k_attn_dkv(const bf16_raw* __restrict__ q
         }
     }
     if (kj < T) {
-        bf16_raw* okp = dqk + ((size_t)b * T + kj) * row2c + C + (size_t)h * CH;
-        bf16_raw* ovp = dv + ((size_t)b * T + kj) * C + (size_t)h * CH;
+        bf16_raw* okp = dqk + ((size_t)b * T + kj) * dqk_rs + C + (size_t)h * CH;
+        bf16_raw* ovp = dv + ((size_t)b * T + kj) * dv_rs + (size_t)h * CH;
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
@@ -316,7 +317,7 @@ template <int CH, int KT>
 __global__ __launch_bounds__(256) void k_attn_dq_f32(const float* __restrict__ qk, const float* __restrict__ vt,
                                                      const float* __restrict__ dout, const float* __restrict__ lse,
                                                      const float* __restrict__ delta, float* __restrict__ dqk, int T, int C,
-                                                     float scale_log2e, float scale) {
+                                                     float scale_log2e, float scale, int dqk_rs) {
     constexpr int CP = CH / 4;
     __shared__ float k_lds[KT][CH + 1];
     __shared__ float v_lds[KT][CH + 1];
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(256) void k_attn_dq_f32(const float* __restrict__ q
     }
     if (qi < T) {
 #pragma unroll
-        for (int c = 0; c < CP; ++c) dqk[((size_t)b * T + qi) * row2c + (size_t)h * CH + part * CP + c] = dq[c];
+        for (int c = 0; c < CP; ++c) dqk[((size_t)b * T + qi) * dqk_rs + (size_t)h * CH + part * CP + c] = dq[c];
     }
 }
 
@@ -369,7 +370,8 @@ template <int CH, int QT>
 __global__ __launch_bounds__(256) void k_attn_dkv_f32(const float* __restrict__ qk, const float* __restrict__ vt,
                                                       const float* __restrict__ dout, const float* __restrict__ lse,
                                                       const float* __restrict__ delta, float* __restrict__ dqk,
-                                                      float* __restrict__ dv, int T, int C, float scale_log2e, float scale) {
+                                                      float* __restrict__ dv, int T, int C, float scale_log2e, float scale,
+                                                      int dqk_rs, int dv_rs) {
     constexpr int CP = CH / 4;
     __shared__ float q_lds[QT][CH + 1];
     __shared__ float d_lds[QT][CH + 1];
@@ -422,8 +424,8 @@ __global__ __launch_bounds__(256) void k_attn_dkv_f32(const float* __restrict__ 
     if (kj < T) {
 #pragma unroll
         for (int c = 0; c < CP; ++c) {
-            dqk[((size_t)b * T + kj) * row2c + C + (size_t)h * CH + part * CP + c] = dk[c];
-            dv[((size_t)b * T + kj) * C + (size_t)h * CH + part * CP + c] = dvv[c];
+            dqk[((size_t)b * T + kj) * dqk_rs + C + (size_t)h * CH + part * CP + c] = dk[c];
+            dv[((size_t)b * T + kj) * dv_rs + (size_t)h * CH + part * CP + c] = dvv[c];
         }
     }
 }
@@ -431,11 +433,12 @@ __global__ __launch_bounds__(256) void k_attn_dkv_f32(const float* __restrict__ 
 // qk [B,T,2C], vt [B,C,T], o / dout [B,T,C] channels-last; lse, delta_ws float32 [B,heads,T];
 // outputs: dqk [B,T,2C] (dq | dk), dv [B,T,C], both channels-last in `dtype`.
 extern "C" int rho_attention_bwd(const void* qk, const void* vt, const void* o, const void* dout, const float* lse,
-                                 float* delta_ws, void* dqk, void* dv, int dtype, int64_t batch, int64_t t, int64_t heads,
-                                 int64_t ch, void* stream) {
+                                 float* delta_ws, void* dqk, int64_t dqk_row_stride, void* dv, int64_t dv_row_stride, int dtype,
+                                 int64_t batch, int64_t t, int64_t heads, int64_t ch, void* stream) {
     if (!qk || !vt || !o || !dout || !lse || !delta_ws || !dqk || !dv || batch <= 0 || t <= 0 || heads <= 0) return RHO_E_ARG;
     if (dtype != RHO_BF16 && dtype != RHO_F32) return RHO_E_ARG;
     const int C = (int)(heads * ch);
+    const int qrs = (int)(dqk_row_stride > 0 ? dqk_row_stride : 2 * C), vrs = (int)(dv_row_stride > 0 ? dv_row_stride : C);
     const float scale = (float)(1.0 / sqrt((double)ch));
     const float sl2 = (float)(1.4426950408889634 / sqrt((double)ch));
     hipStream_t st = as_stream(stream);
@@ -452,9 +455,9 @@ extern "C" int rho_attention_bwd(const void* qk, const void* vt, const void* o, 
 #define RHO_ATTB(chv, ktv)                                                                                                     \
     case chv:                                                                                                                  \
         hipLaunchKernelGGL((k_attn_dq<chv, ktv>), grid, block, 0, st, (const bf16_raw*)qk, (const bf16_raw*)vt,                  \
-                           (const bf16_raw*)dout, lse, delta_ws, (bf16_raw*)dqk, (int)t, C, sl2, scale);                        \
+                           (const bf16_raw*)dout, lse, delta_ws, (bf16_raw*)dqk, (int)t, C, sl2, scale, qrs);                   \
         hipLaunchKernelGGL((k_attn_dkv<chv, ktv>), grid, block, 0, st, (const bf16_raw*)qk, (const bf16_raw*)vt,                 \
-                           (const bf16_raw*)dout, lse, delta_ws, (bf16_raw*)dqk, (bf16_raw*)dv, (int)t, C, sl2, scale);         \
+                           (const bf16_raw*)dout, lse, delta_ws, (bf16_raw*)dqk, (bf16_raw*)dv, (int)t, C, sl2, scale, qrs, vrs); \
         break;
         switch (ch) {
             RHO_ATTB(16, 64)
@@ -471,9 +474,9 @@ extern "C" int rho_attention_bwd(const void* qk, const void* vt, const void* o, 
 #define RHO_ATTB32(chv, ktv)                                                                                                  \
     case chv:                                                                                                                 \
         hipLaunchKernelGGL((k_attn_dq_f32<chv, ktv>), grid, block, 0, st, (const float*)qk, (const float*)vt,                  \
-                           (const float*)dout, lse, delta_ws, (float*)dqk, (int)t, C, sl2, scale);                             \
+                           (const float*)dout, lse, delta_ws, (float*)dqk, (int)t, C, sl2, scale, qrs);                        \
         hipLaunchKernelGGL((k_attn_dkv_f32<chv, ktv>), grid, block, 0, st, (const float*)qk, (const float*)vt,                 \
-                           (const float*)dout, lse, delta_ws, (float*)dqk, (float*)dv, (int)t, C, sl2, scale);                 \
+                           (const float*)dout, lse, delta_ws, (float*)dqk, (float*)dv, (int)t, C, sl2, scale, qrs, vrs);       \
         break;
         switch (ch) {
             RHO_ATTB32(16, 64)

@@ -480,7 +480,7 @@ extern "C" int rho_pool2x_sum(const void* dy, void* dx, int dtype, int64_t n_tim
 // Backward of rho_linear (out = W act(x) + b [+ add]):  dW[o,k] (+)= sum_b dout[b,o] act(x[b,k]),  db[o] (+)= sum_b dout[b,o]
 __global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ dout, const float* __restrict__ x,
                                                       float* __restrict__ dw, float* __restrict__ db, int batch, int in_dim,
-                                                      int out_dim, int act_in, int accumulate) {
+                                                      int out_dim, int act_in, int accumulate, int64_t dstride) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)out_dim * in_dim) return;
     const int o = (int)(i / in_dim), k = (int)(i % in_dim);
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ 
     for (int b = 0; b < batch; ++b) {
         float xv = x[(int64_t)b * in_dim + k];
         if (act_in) xv = xv / (1.0f + expf(-xv));
-        const float g = dout[(int64_t)b * out_dim + o];
+        const float g = dout[(int64_t)b * dstride + o];
         acc = fmaf(g, xv, acc);
         accb += g;
     }
@@ -499,12 +499,12 @@ __global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ 
 // dx[b,k] (+)= act'(x[b,k]) * sum_o dout[b,o] W[o,k]
 __global__ __launch_bounds__(256) void k_linear_bwd_x(const float* __restrict__ dout, const float* __restrict__ w,
                                                       const float* __restrict__ x, float* __restrict__ dx, int batch, int in_dim,
-                                                      int out_dim, int act_in, int accumulate) {
+                                                      int out_dim, int act_in, int accumulate, int64_t dstride) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)batch * in_dim) return;
     const int b = (int)(i / in_dim), k = (int)(i % in_dim);
     float acc = 0.0f;
-    for (int o = 0; o < out_dim; ++o) acc = fmaf(dout[(int64_t)b * out_dim + o], w[(int64_t)o * in_dim + k], acc);
+    for (int o = 0; o < out_dim; ++o) acc = fmaf(dout[(int64_t)b * dstride + o], w[(int64_t)o * in_dim + k], acc);
     if (act_in) {
         const float u = x[i];
         const float s = 1.0f / (1.0f + expf(-u));
@@ -513,17 +513,67 @@ __global__ __launch_bounds__(256) void k_linear_bwd_x(const float* __restrict__ 
     dx[i] = accumulate ? dx[i] + acc : acc;
 }
 
-extern "C" int rho_linear_bwd(const float* dout, const float* x, const float* w, float* dw, float* db, float* dx, int64_t batch,
-                              int64_t in_dim, int64_t out_dim, int act_in, int acc_params, int acc_dx, void* stream) {
+extern "C" int rho_linear_bwd(const float* dout, int64_t dout_stride, const float* x, const float* w, float* dw, float* db,
+                              float* dx, int64_t batch, int64_t in_dim, int64_t out_dim, int act_in, int acc_params, int acc_dx,
+                              void* stream) {
     if (!dout || !x || !w || batch <= 0 || in_dim <= 0 || out_dim <= 0) return RHO_E_ARG;
+    const int64_t dstride = dout_stride > 0 ? dout_stride : out_dim;
     if (dw) {
         hipLaunchKernelGGL(k_linear_bwd_w, dim3((unsigned)((out_dim * in_dim + 255) / 256)), dim3(256), 0, as_stream(stream), dout, x, dw,
-                           db, (int)batch, (int)in_dim, (int)out_dim, act_in, acc_params);
+                           db, (int)batch, (int)in_dim, (int)out_dim, act_in, acc_params, dstride);
     }
     if (dx) {
         hipLaunchKernelGGL(k_linear_bwd_x, dim3((unsigned)((batch * in_dim + 255) / 256)), dim3(256), 0, as_stream(stream), dout, w, x, dx,
-                           (int)batch, (int)in_dim, (int)out_dim, act_in, acc_dx);
+                           (int)batch, (int)in_dim, (int)out_dim, act_in, acc_dx, dstride);
     }
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
+// dst += src (channels-last activations / gradients), 16-byte pieces
+template <typename T>
+__global__ __launch_bounds__(256) void k_add_inplace(T* __restrict__ dst, const T* __restrict__ src, int64_t n) {
+    constexpr int PE = 16 / (int)sizeof(T);
+    const int64_t np = n / PE;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < np; i += (int64_t)gridDim.x * blockDim.x) {
+        uint4 a = reinterpret_cast<const uint4*>(dst)[i];
+        const uint4 b = reinterpret_cast<const uint4*>(src)[i];
+        if constexpr (sizeof(T) == 2) {
+            a.x = pack_bf16x2(__uint_as_float(a.x << 16) + __uint_as_float(b.x << 16), __uint_as_float(a.x & 0xFFFF0000u) + __uint_as_float(b.x & 0xFFFF0000u));
+            a.y = pack_bf16x2(__uint_as_float(a.y << 16) + __uint_as_float(b.y << 16), __uint_as_float(a.y & 0xFFFF0000u) + __uint_as_float(b.y & 0xFFFF0000u));
+            a.z = pack_bf16x2(__uint_as_float(a.z << 16) + __uint_as_float(b.z << 16), __uint_as_float(a.z & 0xFFFF0000u) + __uint_as_float(b.z & 0xFFFF0000u));
+            a.w = pack_bf16x2(__uint_as_float(a.w << 16) + __uint_as_float(b.w << 16), __uint_as_float(a.w & 0xFFFF0000u) + __uint_as_float(b.w & 0xFFFF0000u));
+        } else {
+            a.x = __float_as_uint(__uint_as_float(a.x) + __uint_as_float(b.x));
+            a.y = __float_as_uint(__uint_as_float(a.y) + __uint_as_float(b.y));
+            a.z = __float_as_uint(__uint_as_float(a.z) + __uint_as_float(b.z));
+            a.w = __float_as_uint(__uint_as_float(a.w) + __uint_as_float(b.w));
+        }
+        reinterpret_cast<uint4*>(dst)[i] = a;
+    }
+}
+
+extern "C" int rho_add_inplace(void* dst, const void* src, int dtype, int64_t n, void* stream) {
+    const int pe = dtype == RHO_BF16 ? 8 : 4;
+    if (!dst || !src || n <= 0 || n % pe) return RHO_E_ARG;
+    if (dtype == RHO_BF16)
+        hipLaunchKernelGGL(k_add_inplace<bf16_raw>, dim3(grid_for(n / pe, 256)), dim3(256), 0, as_stream(stream), (bf16_raw*)dst, (const bf16_raw*)src, n);
+    else if (dtype == RHO_F32)
+        hipLaunchKernelGGL(k_add_inplace<float>, dim3(grid_for(n / pe, 256)), dim3(256), 0, as_stream(stream), (float*)dst, (const float*)src, n);
+    else
+        return RHO_E_ARG;
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
+// x *= *scale_dev  (upstream scalar of loss.backward(), read on the device: no host sync)
+__global__ __launch_bounds__(256) void k_scale_dev(float* __restrict__ x, const float* __restrict__ scale_dev, int64_t n) {
+    const float sc = *scale_dev;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] *= sc;
+}
+extern "C" int rho_scale_by_device_scalar(float* x, const float* scale_dev, int64_t n, void* stream) {
+    if (!x || !scale_dev || n <= 0) return RHO_E_ARG;
+    hipLaunchKernelGGL(k_scale_dev, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), x, scale_dev, n);
     RHO_LAUNCH_CHECK();
     return 0;
 }

@@ -159,7 +159,11 @@ class DDPM(AbstractDiffusionPipeline):
             pred_noise = self.backbone(x_data, t, labels)
         else:
             pred_noise = self.backbone(x_data, t)
-        loss = self.loss_func(pred_noise, noise)
+        if isinstance(self.loss_func, nn.MSELoss) and self.loss_func.reduction == "mean":
+            from ..autograd import mse_loss
+            loss = mse_loss(pred_noise, noise)           # HIP reduction + gradient (rho_mse)
+        else:
+            loss = self.loss_func(pred_noise, noise)
         self.log("train_loss", loss, prog_bar=True)
         return loss
 

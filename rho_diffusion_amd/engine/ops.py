@@ -324,21 +324,29 @@ def pool2x_sum(dy: Tensor, dx: Tensor, up_hw, accumulate: bool = False) -> Tenso
     return dx
 
 
-def linear_bwd(dout: Tensor, x: Tensor, w: Tensor, dw: Optional[Tensor], db: Optional[Tensor], dx: Optional[Tensor],
-               act_in: bool = False, acc_params: bool = False, acc_dx: bool = False) -> None:
+def linear_bwd(dout, x: Tensor, w: Tensor, dw: Optional[Tensor], db: Optional[Tensor], dx: Optional[Tensor],
+               act_in: bool = False, acc_params: bool = False, acc_dx: bool = False, dout_stride: int = 0) -> None:
+    """dout may be a tensor or a raw device pointer (a column slice of the batched FiLM gradient)."""
     B, K = x.shape
     O = w.shape[0]
-    check(hip.lib().rho_linear_bwd(ptr(dout), ptr(x), ptr(w), ptr(dw), ptr(db), ptr(dx), B, K, O, int(act_in), int(acc_params),
-                                   int(acc_dx), stream()), "rho_linear_bwd")
+    dp = dout if isinstance(dout, int) else dout.data_ptr()
+    check(hip.lib().rho_linear_bwd(dp, dout_stride, ptr(x), ptr(w), ptr(dw), ptr(db), ptr(dx), B, K, O, int(act_in),
+                                   int(acc_params), int(acc_dx), stream()), "rho_linear_bwd")
 
 
-def attention_bwd(qk: Tensor, vt: Tensor, o: Tensor, dout: Tensor, lse: Tensor, heads: int, dqk: Optional[Tensor] = None,
-                  dv: Optional[Tensor] = None, delta_ws: Optional[Tensor] = None):
+def add_inplace(dst: Tensor, src: Tensor) -> None:
+    check(hip.lib().rho_add_inplace(ptr(dst), ptr(src), dtype_code(dst.dtype), dst.numel(), stream()), "rho_add_inplace")
+
+
+def attention_bwd(qk: Tensor, vt: Tensor, o: Tensor, dout: Tensor, lse: Tensor, heads: int, dqkv: Optional[Tensor] = None,
+                  delta_ws: Optional[Tensor] = None):
+    """Returns dqkv channels-last [B, T, 3C] = (dq | dk | dv): the output gradient of the qkv projection."""
     B, T, C2 = qk.shape
     Cc = C2 // 2
-    dqk = torch.empty_like(qk) if dqk is None else dqk
-    dv = torch.empty(B, T, Cc, dtype=qk.dtype, device=qk.device) if dv is None else dv
+    dqkv = torch.empty(B, T, 3 * Cc, dtype=qk.dtype, device=qk.device) if dqkv is None else dqkv
     delta_ws = torch.empty(B, heads, T, dtype=torch.float32, device=qk.device) if delta_ws is None else delta_ws
-    check(hip.lib().rho_attention_bwd(ptr(qk), ptr(vt), ptr(o), ptr(dout), ptr(lse), ptr(delta_ws), ptr(dqk), ptr(dv),
-                                      dtype_code(qk.dtype), B, T, heads, Cc // heads, stream()), "rho_attention_bwd")
-    return dqk, dv
+    esz = dqkv.element_size()
+    check(hip.lib().rho_attention_bwd(ptr(qk), ptr(vt), ptr(o), ptr(dout), ptr(lse), ptr(delta_ws), dqkv.data_ptr(), 3 * Cc,
+                                      dqkv.data_ptr() + 2 * Cc * esz, 3 * Cc, dtype_code(qk.dtype), B, T, heads, Cc // heads,
+                                      stream()), "rho_attention_bwd")
+    return dqkv

@@ -1,19 +1,30 @@
-"""Lowering of a ``UNet`` module tree (models/unet_v2.py) to a flat list of HIP kernel launches.
+"""Lowering of a ``UNet`` module tree (models/unet_v2.py) to flat lists of HIP kernel launches,
+forward AND backward.
 
 Reference semantics: UNet.forward, rho_diffusion/models/unet_v2.py:685-732, with ResBlock._forward
 (:273-293), AttentionBlock._forward (:336-342), Downsample / Upsample (:103-169) and the final
-GroupNorm-SiLU-conv (:679-683).
+GroupNorm-SiLU-conv (:679-683); the backward is what torch autograd derives for those ops.
 
-Per forward and per ResBlock the launches are:
+Forward, per ResBlock:
     gn_partial, gn_finalize            statistics + folded (GroupNorm * FiLM) affine per (n, c)
     conv3   (prologue: affine+SiLU)    in_layers   [+ additive embedding in the epilogue]
     gn_partial, gn_finalize
     [conv1x1 skip]
     conv3   (prologue: affine+SiLU, epilogue: + skip)
 torch.cat of the skip connections, nearest-upsample, strides, SiLU, FiLM and residual adds never
-exist as separate passes over HBM.  A plan (all descriptors + all buffers) is built once per
-(batch, spatial shape) and replayed; buffer addresses are stable so the replay can be captured in
-a HIP graph.  PyTorch supplies memory and streams only.
+exist as separate passes over HBM.
+
+Backward, per conv: bias gradient (channel sums of dY), weight gradient (rho_conv_nd_wgrad, input
+activation recomputed in its loader), data gradient (the forward kernel on dY with flipped /
+transposed weights) followed by the GroupNorm+FiLM+SiLU backward (reduce / finalize / apply).
+Only pre-norm activations, GroupNorm statistics and the attention log-sum-exp are kept from the
+forward; normalised / activated tensors and attention probabilities are recomputed (the reference
+recomputes attention too, unet_v2.py:334).  Where a tensor has several consumers its gradient
+buffer is aliased (identity skips, residuals) or accumulated in the producing kernel's epilogue;
+the choice is made once, when the plan is built.
+
+A plan (all descriptors + all buffers) is built once per (batch, spatial shape, mode) and replayed;
+buffer addresses are stable.  PyTorch supplies memory and streams only.
 """
 from __future__ import annotations
 
@@ -31,24 +42,41 @@ Tensor = torch.Tensor
 
 
 class _ConvW:
-    """A conv weight prepared for the kernel: [taps, coutp, cinp] in the engine dtype + padded fp32 bias."""
+    """A conv weight prepared for the kernels: forward [taps, coutp, cinp] and (training) data-gradient
+    [taps, ceil32(cin), coutp] layouts in the engine dtype + padded fp32 bias."""
 
-    def __init__(self, weight: nn.Parameter, bias: nn.Parameter, dtype, row_src: Optional[Tensor] = None,
-                 cout_pad_to: int = 32):
+    def __init__(self, weight: nn.Parameter, bias: nn.Parameter, dtype, row_src: Optional[Tensor] = None):
         self.weight, self.bias_param, self.dtype = weight, bias, dtype
         self.cout, self.cin = weight.shape[0], weight.shape[1]
         k = list(weight.shape[2:])
         while len(k) < 3:
             k.insert(0, 1)
         self.kernel = tuple(int(v) for v in k)
+        self.taps = int(k[0] * k[1] * k[2])
         ck = ops.elem_chunk(dtype)
         self.cinp = ((self.cin + ck - 1) // ck) * ck
-        self.coutp = ((self.cout + cout_pad_to - 1) // cout_pad_to) * cout_pad_to
+        self.coutp = ((self.cout + 31) // 32) * 32
         self.row_src = row_src
         dev = weight.device
-        self.w = torch.empty(int(k[0] * k[1] * k[2]), self.coutp, self.cinp, dtype=dtype, device=dev)
+        self.w = torch.empty(self.taps, self.coutp, self.cinp, dtype=dtype, device=dev)
         self.b = torch.zeros(self.coutp, dtype=torch.float32, device=dev)
+        self.wd: Optional[Tensor] = None     # dgrad weights, allocated with the first training plan
+        self.zero_bias: Optional[Tensor] = None
         self.refresh()
+
+    def enable_dgrad(self) -> None:
+        if self.wd is None:
+            rows = ((self.cin + 31) // 32) * 32
+            self.wd = torch.empty(self.taps, rows, self.coutp, dtype=self.dtype, device=self.w.device)
+            self.zero_bias = torch.zeros(rows, dtype=torch.float32, device=self.w.device)
+            self._refresh_dgrad()
+
+    def _refresh_dgrad(self) -> None:
+        w = self.weight.detach()
+        w = w if w.is_contiguous() else w.contiguous()
+        check(hip.lib().rho_prep_conv_weight_dgrad(ptr(w), ptr(self.wd), hip.dtype_code(self.dtype), self.cout, self.cin, self.taps,
+                                                   self.wd.shape[1], self.wd.shape[2], ptr(self.row_src), hip.stream()),
+              "rho_prep_conv_weight_dgrad")
 
     def refresh(self) -> None:
         w = self.weight.detach()
@@ -59,6 +87,29 @@ class _ConvW:
         if self.row_src is not None:
             b = b[self.row_src.long()]           # gather (data movement only)
         self.b[: b.numel()].copy_(b)
+        if self.wd is not None:
+            self._refresh_dgrad()
+
+
+class _Pool:
+    """Exact-size buffer pool for backward temporaries (emission order == stream order)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.free: Dict[tuple, List[Tensor]] = {}
+        self.all: List[Tensor] = []
+
+    def get(self, shape, dtype) -> Tensor:
+        key = (int(torch.Size(shape).numel()), dtype)
+        lst = self.free.get(key)
+        if lst:
+            return lst.pop().view(*shape)
+        t = torch.empty(*shape, dtype=dtype, device=self.device)
+        self.all.append(t)
+        return t
+
+    def put(self, t: Tensor) -> None:
+        self.free.setdefault((t.numel(), t.dtype), []).append(t)
 
 
 class UNetEngine:
@@ -79,6 +130,8 @@ class UNetEngine:
         self._sin_table: Optional[Tensor] = None
         self._sin_rows = 0
         self._param_version = -1
+        self._ptr_sig = None
+        self._last_train_plan: Optional["_Plan"] = None
         with torch.inference_mode(False):
             self._collect()
             self.refresh_weights(force=True)
@@ -138,8 +191,18 @@ class UNetEngine:
     def _versions(self) -> int:
         return sum(p._version for p in self.model.parameters())
 
+    def _pointer_signature(self) -> int:
+        return hash(tuple(p.data_ptr() for p in self.model.parameters()))
+
     def refresh_weights(self, force: bool = False) -> None:
-        """Re-run the weight preparation kernels if any parameter changed (optimizer step, load_state_dict)."""
+        """Re-run the weight preparation kernels if any parameter changed (optimizer step, load_state_dict);
+        drop the plans if parameter storage moved (e.g. re-homed into an optimizer arena)."""
+        sig = self._pointer_signature()
+        if self._ptr_sig is not None and sig != self._ptr_sig:
+            self._plans.clear()
+            self._last_train_plan = None
+            force = True
+        self._ptr_sig = sig
         v = self._versions()
         if not force and v == self._param_version:
             return
@@ -165,50 +228,81 @@ class UNetEngine:
             self._sin_rows = rows
         return self._sin_table
 
-    # ------------------------------------------------------------------ forward
+    def param_order(self) -> List[nn.Parameter]:
+        """Embedding-path parameters first (their gradients complete last), then every other parameter in
+        forward order: backward finalises gradients from the tail of this list to its head, so contiguous
+        ranges of an optimizer arena laid out this way are ready-made data-parallel all-reduce buckets."""
+        emb = list(self.model.time_embed.parameters())
+        for blk in self._film_blocks:
+            emb.extend(blk.emb_layers[1].parameters())
+        if getattr(self.model, "cond_fn", None) is not None:
+            emb.extend(self.model.cond_fn.parameters())
+        emb_ids = {id(p_) for p_ in emb}
+        main = [p_ for p_ in self.model.parameters() if id(p_) not in emb_ids]
+        return emb + main
+
+    # ------------------------------------------------------------------ forward / backward
     def forward(self, x: Tensor, timesteps: Tensor, y: Optional[Tensor] = None,
-                t_scalar_dev: Optional[Tensor] = None) -> Tensor:
+                t_scalar_dev: Optional[Tensor] = None, train: bool = False) -> Tensor:
         hip.require_gpu(x, "x")
         if x.dtype != torch.float32:
             x = x.float()
         x = x.contiguous()
-        key = (tuple(x.shape), y is not None)
+        self.refresh_weights()
+        key = (tuple(x.shape), y is not None, bool(train))
         plan = self._plans.get(key)
         if plan is None:
-            with torch.inference_mode(False):     # plan buffers must stay ordinary tensors
-                plan = self._plans[key] = _Plan(self, tuple(x.shape), y is not None)
-        self.refresh_weights()
+            with torch.inference_mode(False), torch.no_grad():     # plan buffers must stay ordinary tensors
+                plan = self._plans[key] = _Plan(self, tuple(x.shape), y is not None, bool(train))
+        if train:
+            self._last_train_plan = plan
         return plan.run(x, timesteps, y, t_scalar_dev)
+
+    def backward(self, dpred: Tensor, on_ready: Optional[Callable[[List[nn.Parameter]], None]] = None) -> None:
+        """Backward of the most recent ``forward(train=True)``: accumulates into ``p.grad`` of every
+        parameter (allocated as zeros if missing).  ``on_ready(params)`` is called as groups of
+        parameter gradients become final (used to overlap the data-parallel all-reduce)."""
+        plan = self._last_train_plan
+        if plan is None:
+            raise hip.RhoHipError("backward() without a preceding forward(train=True)")
+        with torch.no_grad():
+            plan.run_backward(dpred, on_ready)
 
 
 class _Plan:
-    """All buffers + launch closures for one input shape."""
+    """All buffers + launch closures for one input shape (forward, and backward when train=True)."""
 
-    def __init__(self, eng: UNetEngine, xshape: Tuple[int, ...], has_y: bool):
+    def __init__(self, eng: UNetEngine, xshape: Tuple[int, ...], has_y: bool, train: bool):
         from ..models.unet_v2 import AttentionBlock, Downsample, ResBlock, Upsample
         self.eng = eng
+        self.train = train
         m = eng.model
         dt = eng.dtype
+        dtc = hip.dtype_code(dt)
         dev = eng.device
         self.ops: List[Callable[[int], int]] = []
         self.info: List[dict] = []     # per launch: kind, algorithmic flops / bytes (for bench roofline)
         self.keep: List[object] = []   # descriptors / tensors referenced by raw pointers
+        self.nodes: List[dict] = []
+        self.cond_src = None
         L = hip.lib()
+        self.L = L
         B = xshape[0]
         self.B = B
         self.xshape = xshape
         D, H, W = ops.spatial5(xshape[2:])
         dims = eng.dims
         e = 4 * eng.mc
+        esz = 2 if dt == torch.bfloat16 else 4
 
         def buf(*shape, dtype=dt):
             t = torch.empty(*shape, dtype=dtype, device=dev)
             self.keep.append(t)
             return t
 
-        # ---- embedding chain: table gather -> Linear -> SiLU -> Linear (+cond) -> batched FiLM GEMV
+        # ---- embedding chain: table gather -> Linear -> (SiLU) Linear (+cond) -> (SiLU) batched FiLM GEMV
         self.sin_in = buf(B, eng.mc, dtype=torch.float32)
-        self.emb_h = buf(B, e, dtype=torch.float32)
+        self.emb_h = buf(B, e, dtype=torch.float32)     # PRE-activation of time_embed[0]; the consumer applies SiLU
         self.emb = buf(B, e, dtype=torch.float32)
         self.cond = buf(B, e, dtype=torch.float32) if has_y else None
         self.film = buf(B, max(eng.film_total, 1), dtype=torch.float32)
@@ -222,8 +316,8 @@ class _Plan:
             self.ops.append(lambda s, a=args: L.rho_linear(*a, s))
             self.info.append(dict(kind="linear", flops=2.0 * Bn * K * O, bytes=4.0 * (O * K + Bn * (K + O))))
 
-        op_linear(self.sin_in, te0.weight, te0.bias, None, self.emb_h, False, True)
-        op_linear(self.emb_h, te2.weight, te2.bias, self.cond, self.emb, False, False)
+        op_linear(self.sin_in, te0.weight, te0.bias, None, self.emb_h, False, False)
+        op_linear(self.emb_h, te2.weight, te2.bias, self.cond, self.emb, True, False)
         if eng.film_total:
             op_linear(self.emb, eng.film_w, eng.film_b, None, self.film, True, False)
 
@@ -241,71 +335,69 @@ class _Plan:
             st = buf(N, 32, 2, dtype=torch.float32)
             scale = shift = None
             stride = 0
+            off = None
             if film_blk is not None:
                 off = eng._film_off[id(film_blk)]
                 scale = self.film.data_ptr() + 4 * off
                 shift = self.film.data_ptr() + 4 * (off + Cc)
                 stride = self.film.shape[1]
-            a1 = (ptr(x1), c1, ptr(x2), c2, hip.dtype_code(dt), N, S, ptr(part))
+            a1 = (ptr(x1), c1, ptr(x2), c2, dtc, N, S, ptr(part))
             a2 = (ptr(part), N, Cc, S, nblk, ptr(norm.weight), ptr(norm.bias), scale, shift, stride, ptr(st), ptr(a), ptr(b))
-            esz = 2 if dt == torch.bfloat16 else 4
             self.ops.append(lambda s, a=a1: L.rho_gn_partial(*a, s))
             self.info.append(dict(kind="gn_partial", flops=3.0 * N * S * Cc, bytes=float(esz) * N * S * Cc))
             self.ops.append(lambda s, a=a2: L.rho_gn_finalize(*a, s))
             self.info.append(dict(kind="gn_finalize", flops=0.0, bytes=4.0 * N * Cc * 4))
-            return a, b
+            return dict(x1=x1, x2=x2, norm=norm, film_off=off, a=a, b=b, st=st, part=part, N=N, S=S, C=Cc, nblk=nblk)
 
-        def conv(x1, x2, cw, *, stride_hw=(1, 1), up_hw=(0, 0), pre=None, pre_silu=False, res=None, res_add=None,
-                 res_add_stride=0, split=None, y2_dtype=None):
+        def conv(x1, x2, cw, *, stride_hw=(1, 1), up_hw=(0, 0), pre=None, pre_silu=False, res=None, res_add_off=None,
+                 split=None, y2_dtype=None, stem=False):
             cout = cw.cout
             split_ = cout if split is None else split
             N, Do, Ho, Wo = ops.conv_out_shape(x1.shape, cw.kernel, stride_hw, up_hw)
             y = buf(N, Do, Ho, Wo, split_) if split_ > 0 else None
             y2 = buf(N, cout - split_, Do * Ho * Wo, dtype=y2_dtype or dt) if split_ < cout else None
             d = ops.make_conv_desc(x1, x2, cw.w, cw.b, kernel=cw.kernel, cout=cout, split=split_, y=y, y2=y2,
-                                   stride_hw=stride_hw, up_hw=up_hw, pre_a=pre[0] if pre else None,
-                                   pre_b=pre[1] if pre else None, pre_silu=pre_silu, res=res, res_add=None,
-                                   res_add_stride=res_add_stride)
-            if res_add is not None:
-                d.res_add = res_add
+                                   stride_hw=stride_hw, up_hw=up_hw, pre_a=pre["a"] if pre else None,
+                                   pre_b=pre["b"] if pre else None, pre_silu=pre_silu, res=res, res_add=None)
+            if res_add_off is not None:
+                d.res_add = self.film.data_ptr() + 4 * res_add_off
+                d.res_add_stride = self.film.shape[1]
             self.keep.append(d)
             self.ops.append(lambda s, d=d: L.rho_conv_nd_fwd(C.byref(d), s))
-            taps = cw.kernel[0] * cw.kernel[1] * cw.kernel[2]
-            esz = 2 if dt == torch.bfloat16 else 4
             npos_out = N * Do * Ho * Wo
             npos_in = x1.numel() // x1.shape[-1]
             self.info.append(dict(
-                kind="conv3" if taps > 1 else "conv1", taps=taps, cin=cw.cin, cout=cout, positions=npos_out,
-                flops=2.0 * npos_out * cout * cw.cin * taps,                       # algorithmic (unpadded) MACs * 2
-                bytes=float(esz) * (npos_in * cw.cin + npos_out * cout * (2 if res is not None else 1) + taps * cout * cw.cin)))
+                kind="conv3" if cw.taps > 1 else "conv1", taps=cw.taps, cin=cw.cin, cout=cout, positions=npos_out,
+                flops=2.0 * npos_out * cout * cw.cin * cw.taps,                       # algorithmic (unpadded) MACs * 2
+                bytes=float(esz) * (npos_in * cw.cin + npos_out * cout * (2 if res is not None else 1) + cw.taps * cout * cw.cin)))
+            self.nodes.append(dict(k="conv", cw=cw, x1=x1, x2=x2, y=y, y2=y2, stride_hw=stride_hw, up_hw=up_hw, pre=pre,
+                                   pre_silu=pre_silu, res=res, res_add_off=res_add_off, stem=stem, out_dims=(N, Do, Ho, Wo)))
             return y, y2
 
         def resblock(blk, h1, h2):
-            a1, b1 = gn(h1, h2, blk.in_layers[0])
-            radd, rstride = None, 0
-            if not blk.use_scale_shift_norm:
-                radd = self.film.data_ptr() + 4 * eng._film_off[id(blk)]
-                rstride = self.film.shape[1]
-            t1, _ = conv(h1, h2, eng._conv(blk.in_layers[2]), pre=(a1, b1), pre_silu=True, res_add=radd, res_add_stride=rstride)
-            a2, b2 = gn(t1, None, blk.out_layers[0], film_blk=blk if blk.use_scale_shift_norm else None)
+            g1 = gn(h1, h2, blk.in_layers[0])
+            radd = None if blk.use_scale_shift_norm else eng._film_off[id(blk)]
+            t1, _ = conv(h1, h2, eng._conv(blk.in_layers[2]), pre=g1, pre_silu=True, res_add_off=radd)
+            g2 = gn(t1, None, blk.out_layers[0], film_blk=blk if blk.use_scale_shift_norm else None)
             if isinstance(blk.skip_connection, nn.Identity):
                 assert h2 is None
                 sk = h1
             else:
                 sk, _ = conv(h1, h2, eng._conv(blk.skip_connection))
-            out, _ = conv(t1, None, eng._conv(blk.out_layers[3]), pre=(a2, b2), pre_silu=True, res=sk)
+            out, _ = conv(t1, None, eng._conv(blk.out_layers[3]), pre=g2, pre_silu=True, res=sk)
             return out
 
         def attention(blk, xin):
             N, Dd, Hh, Ww, Cc = xin.shape
             T = Dd * Hh * Ww
-            a, b = gn(xin, None, blk.norm)
-            qk, vt = conv(xin, None, eng._conv(blk.qkv), pre=(a, b), pre_silu=False, split=2 * Cc)
+            g = gn(xin, None, blk.norm)
+            qk, vt = conv(xin, None, eng._conv(blk.qkv), pre=g, pre_silu=False, split=2 * Cc)
             ao = buf(N, Dd, Hh, Ww, Cc)
-            args = (ptr(qk), ptr(vt), ptr(ao), None, hip.dtype_code(dt), N, T, blk.num_heads, Cc // blk.num_heads)
+            lse = buf(N, blk.num_heads, T, dtype=torch.float32) if train else None
+            args = (ptr(qk), ptr(vt), ptr(ao), ptr(lse), dtc, N, T, blk.num_heads, Cc // blk.num_heads)
             self.ops.append(lambda s, a=args: L.rho_attention_fwd(*a, s))
-            esz = 2 if dt == torch.bfloat16 else 4
             self.info.append(dict(kind="attention", flops=4.0 * N * T * T * Cc, bytes=float(esz) * 4 * N * T * Cc))
+            self.nodes.append(dict(k="attn", qk=qk, vt=vt, ao=ao, lse=lse, heads=blk.num_heads, N=N, T=T, C=Cc))
             out, _ = conv(ao, None, eng._conv(blk.proj_out), res=xin)
             return out
 
@@ -322,14 +414,14 @@ class _Plan:
                     up = (1, 1) if dims >= 2 else (0, 1)
                     h1, _ = conv(h1, None, eng._conv(layer.conv), up_hw=up)
                 else:  # the stem conv
-                    h1, _ = conv(h1, None, eng._conv(layer))
+                    h1, _ = conv(h1, None, eng._conv(layer), stem=True)
             return h1
 
         # ---- the network
         stem = eng._conv(m.input_blocks[0][0])
         self.x_in = buf(*xshape, dtype=torch.float32)
         self.x_cl = buf(B, D, H, W, stem.cinp)
-        pk = (ptr(self.x_in), ptr(self.x_cl), hip.dtype_code(dt), B, xshape[1], D * H * W, stem.cinp)
+        pk = (ptr(self.x_in), ptr(self.x_cl), dtc, B, xshape[1], D * H * W, stem.cinp)
         self.ops.append(lambda s, a=pk: L.rho_pack_input(*a, s))
         self.info.append(dict(kind="pack", flops=0.0, bytes=4.0 * B * xshape[1] * D * H * W + 2.0 * B * D * H * W * stem.cinp))
 
@@ -341,10 +433,253 @@ class _Plan:
         h = run_block(m.middle_block, h, None)
         for blk in m.output_blocks:
             h = run_block(blk, h, hs.pop())
-        a, b = gn(h, None, m.out[0])
-        _, y2 = conv(h, None, eng._conv(m.out[2]), pre=(a, b), pre_silu=True, split=0, y2_dtype=torch.float32)
+        g = gn(h, None, m.out[0])
+        _, y2 = conv(h, None, eng._conv(m.out[2]), pre=g, pre_silu=True, split=0, y2_dtype=torch.float32)
         self.out = y2.view(B, m.out_channels, *xshape[2:])
 
+        self.bwd: List[Callable[[int], int]] = []
+        self.bwd_info: List[dict] = []
+        self.bwd_marks: List[Tuple[int, List[nn.Parameter]]] = []   # after bwd[:i] these parameters' gradients are final
+        if train:
+            self._build_backward()
+
+    # ------------------------------------------------------------------ backward construction
+    def _build_backward(self) -> None:
+        eng, L = self.eng, self.L
+        m = eng.model
+        dt = eng.dtype
+        dtc = hip.dtype_code(dt)
+        dev = eng.device
+        B = self.B
+        pool = _Pool(dev)
+        self.keep.append(pool)
+        for cw in eng._convs:
+            cw.enable_dgrad()
+        G: Dict[int, Tensor] = {}        # activation data_ptr -> gradient buffer
+        written = set()
+        bw, binfo = self.bwd, self.bwd_info
+        esz = 2 if dt == torch.bfloat16 else 4
+
+        def key(t: Tensor) -> int:
+            return t.data_ptr()
+
+        def emit(fn, kind, flops=0.0, nbytes=0.0):
+            bw.append(fn)
+            binfo.append(dict(kind=kind, flops=flops, bytes=nbytes))
+
+        def gradbuf(t: Tensor):
+            """(buffer, accumulate?) for a write into the gradient of activation t."""
+            k = key(t)
+            if k in G:
+                return G[k], (k in written)
+            G[k] = pool.get(tuple(t.shape), t.dtype)
+            return G[k], False
+
+        # scratch shared by all layers (stream-ordered reuse)
+        max_w = max(cw.taps * cw.coutp * cw.cinp for cw in eng._convs)
+        dwbuf = torch.empty(max_w, dtype=torch.float32, device=dev)
+        max_c = max(max(cw.coutp, cw.cinp) for cw in eng._convs)
+        nc_tmp = torch.empty(B * max(max_c, 64), dtype=torch.float32, device=dev)
+        c_tmp = torch.empty(max(max_c, 64), dtype=torch.float32, device=dev)
+        self.dfilm = torch.empty(B, max(eng.film_total, 1), dtype=torch.float32, device=dev)
+        self.demb = torch.empty(B, 4 * eng.mc, dtype=torch.float32, device=dev)
+        self.demb_h = torch.empty(B, 4 * eng.mc, dtype=torch.float32, device=dev)
+        self.keep.extend([dwbuf, nc_tmp, c_tmp])
+        film_stride = self.film.shape[1]
+
+        def pgrad(p: nn.Parameter) -> int:
+            return p.grad.data_ptr()       # resolved at launch time: optimizers may re-home .grad
+
+        def bias_and_wgrad(node, dY: Tensor, dyw: int):
+            cw = node["cw"]
+            N, Do, Ho, Wo = node["out_dims"]
+            S = Do * Ho * Wo
+            nblk = ops.gn_nblk(S)
+            part = pool.get((N * nblk * (dyw // 8) * 16,), torch.float32)
+            rs = ptr(cw.row_src)
+            # bias gradient: channel sums of dY, then (row-permuted, truncated) accumulate into bias.grad
+            a = (ptr(dY), dtc, N, S, dyw, ptr(part), ptr(nc_tmp), 0, 0, ptr(c_tmp), 0)
+            emit(lambda s, a=a: L.rho_chan_sum(*a, s), "chan_sum", nbytes=float(esz) * N * S * dyw)
+            emit(lambda s, cw=cw, rs=rs, w_=dyw: L.rho_wgrad_finalize(ptr(c_tmp), pgrad(cw.bias_param), cw.cout, 1, 1, w_, 1, rs, 1, s),
+                 "bias_grad")
+            if node["res_add_off"] is not None:        # additive timestep embedding (unet_v2.py:291)
+                dst = self.dfilm.data_ptr() + 4 * node["res_add_off"]
+                a = (ptr(dY), dtc, N, S, dyw, ptr(part), dst, film_stride, 0, None, 0)
+                emit(lambda s, a=a: L.rho_chan_sum(*a, s), "chan_sum", nbytes=float(esz) * N * S * dyw)
+            pool.put(part)
+            # weight gradient (forward descriptor; upsampled input materialised)
+            x1 = node["x1"]
+            tmp_up = None
+            if node["up_hw"] != (0, 0):
+                uh, uw = node["up_hw"]
+                tmp_up = pool.get((x1.shape[0], x1.shape[1], x1.shape[2] * (2 if uh else 1), x1.shape[3] * (2 if uw else 1),
+                                   x1.shape[4]), dt)
+                a = (ptr(x1), ptr(tmp_up), dtc, x1.shape[0] * x1.shape[1], x1.shape[2], x1.shape[3], x1.shape[4], int(uh), int(uw))
+                emit(lambda s, a=a: L.rho_upsample2x(*a, s), "upsample", nbytes=5.0 * esz * x1.numel())
+                x1 = tmp_up
+            pre = node["pre"]
+            d = ops.make_conv_desc(x1, node["x2"], cw.w, cw.b, kernel=cw.kernel, cout=cw.cout, split=cw.cout, y=dY, y2=None,
+                                   stride_hw=node["stride_hw"], pre_a=pre["a"] if pre else None, pre_b=pre["b"] if pre else None,
+                                   pre_silu=node["pre_silu"])
+            self.keep.append(d)
+            nw = cw.taps * cw.coutp * cw.cinp
+            dwv = dwbuf[:nw]
+            emit(lambda s, t=dwv: (t.zero_(), 0)[1], "memset", nbytes=4.0 * nw)
+            emit(lambda s, d=d, dy=ptr(dY), w_=dyw: L.rho_conv_nd_wgrad(C.byref(d), dy, w_, ptr(dwbuf), s), "wgrad",
+                 flops=2.0 * N * S * cw.cout * cw.cin * cw.taps, nbytes=float(esz) * (x1.numel() + dY.numel()))
+            emit(lambda s, cw=cw, rs=rs: L.rho_wgrad_finalize(ptr(dwbuf), pgrad(cw.weight), cw.cout, cw.cin, cw.taps, cw.coutp,
+                                                              cw.cinp, rs, 1, s), "wgrad_finalize", nbytes=8.0 * nw)
+            if tmp_up is not None:
+                pool.put(tmp_up)
+
+        def dgrad(node, dY: Tensor, dyw: int):
+            cw = node["cw"]
+            x1, x2, pre = node["x1"], node["x2"], node["pre"]
+            c1 = x1.shape[-1]
+            c2 = x2.shape[-1] if x2 is not None else 0
+            cin = c1 + c2
+            if dyw != cw.wd.shape[2] or cw.wd.shape[1] != cin:
+                raise hip.RhoHipError("internal: dgrad weight shape does not match the gradient tensors")
+            common = dict(kernel=cw.kernel, cout=cin)
+            if pre is not None or node["up_hw"] != (0, 0):
+                N, Do, Ho, Wo = node["out_dims"]
+                tshape = (N, Do, Ho, Wo, cin) if node["up_hw"] != (0, 0) else tuple(x1.shape[:4]) + (cin,)
+                dact = pool.get(tshape, dt)       # gradient of the activated / upsampled tensor
+                d = ops.make_conv_desc(dY, None, cw.wd, cw.zero_bias, split=cin, y=dact, y2=None, **common)
+                self.keep.append(d)
+                emit(lambda s, d=d: L.rho_conv_nd_fwd(C.byref(d), s), "dgrad",
+                     flops=2.0 * (dact.numel() // cin) * cin * cw.cout * cw.taps, nbytes=float(esz) * (dY.numel() + dact.numel()))
+                if pre is not None:
+                    norm = pre["norm"]
+                    Cc, N_, S_ = pre["C"], pre["N"], pre["S"]
+                    g1, acc1 = gradbuf(x1)
+                    g2, acc2 = gradbuf(x2) if x2 is not None else (None, False)
+                    cA = pool.get((N_, Cc), torch.float32)
+                    cP = pool.get((N_, 32), torch.float32)
+                    cQ = pool.get((N_, 32), torch.float32)
+                    work = pool.get((2 * N_ * Cc,), torch.float32)
+                    scale = dscale = dshift = None
+                    fstride = 0
+                    if pre["film_off"] is not None:
+                        scale = self.film.data_ptr() + 4 * pre["film_off"]
+                        fstride = film_stride
+                        dscale = self.dfilm.data_ptr() + 4 * pre["film_off"]
+                        dshift = self.dfilm.data_ptr() + 4 * (pre["film_off"] + Cc)
+                    a1 = (ptr(dact), ptr(x1), c1, ptr(x2), c2, dtc, N_, S_, ptr(pre["a"]), ptr(pre["b"]), ptr(pre["st"]),
+                          int(node["pre_silu"]), ptr(pre["part"]))
+                    emit(lambda s, a=a1: L.rho_gn_bwd_reduce(*a, s), "gn_bwd_reduce", nbytes=2.0 * esz * N_ * S_ * Cc)
+                    emit(lambda s, pre=pre, norm=norm, scale=scale, fstride=fstride, work=work, dscale=dscale, dshift=dshift,
+                         cA=cA, cP=cP, cQ=cQ, N_=N_, Cc=Cc, S_=S_: L.rho_gn_bwd_finalize(
+                             ptr(pre["part"]), N_, Cc, S_, pre["nblk"], ptr(norm.weight), ptr(norm.bias), scale, fstride, ptr(pre["st"]),
+                             ptr(work), pgrad(norm.weight), pgrad(norm.bias), 1, dscale, dshift, film_stride, ptr(cA), ptr(cP),
+                             ptr(cQ), s), "gn_bwd_finalize")
+                    a3 = (ptr(dact), ptr(x1), c1, ptr(x2), c2, dtc, N_, S_, ptr(pre["a"]), ptr(pre["b"]), int(node["pre_silu"]),
+                          ptr(cA), ptr(cP), ptr(cQ), ptr(g1), ptr(g2), int(acc1), int(acc2))
+                    emit(lambda s, a=a3: L.rho_gn_bwd_apply(*a, s), "gn_bwd_apply", nbytes=3.0 * esz * N_ * S_ * Cc)
+                    written.add(key(x1))
+                    if x2 is not None:
+                        written.add(key(x2))
+                    for t in (cA, cP, cQ, work):
+                        pool.put(t)
+                else:   # upsample: sum the 2x2 (1x2) children
+                    g1, acc1 = gradbuf(x1)
+                    a = (ptr(dact), ptr(g1), dtc, x1.shape[0] * x1.shape[1], x1.shape[2], x1.shape[3], x1.shape[4],
+                         int(node["up_hw"][0]), int(node["up_hw"][1]), int(acc1))
+                    emit(lambda s, a=a: L.rho_pool2x_sum(*a, s), "pool2x", nbytes=5.0 * esz * x1.numel())
+                    written.add(key(x1))
+                pool.put(dact)
+            else:
+                g1, acc1 = gradbuf(x1)
+                g2, acc2 = gradbuf(x2) if x2 is not None else (None, False)
+                st = node["stride_hw"]
+                zs = (int(st[0] == 2), int(st[1] == 2))
+                d = ops.make_conv_desc(dY, None, cw.wd, cw.zero_bias, split=c1, y=g1, y2=g2, y2_cl=x2 is not None,
+                                       res=g1 if acc1 else None, res2=g2 if (x2 is not None and acc2) else None,
+                                       zs_hw=zs, out_hw=(x1.shape[2], x1.shape[3]) if zs != (0, 0) else (0, 0), **common)
+                self.keep.append(d)
+                emit(lambda s, d=d: L.rho_conv_nd_fwd(C.byref(d), s), "dgrad",
+                     flops=2.0 * (x1.numel() // c1) * cin * cw.cout * cw.taps, nbytes=float(esz) * (dY.numel() + x1.numel()))
+                written.add(key(x1))
+                if x2 is not None:
+                    written.add(key(x2))
+
+        # ---- head: dpred [N, Cout, S] float32 -> channels-last, as wide as the dgrad weights expect
+        self.dpred_in = torch.empty(tuple(self.out.shape), dtype=torch.float32, device=dev)
+        head = self.nodes[-1]
+        hw = head["cw"].wd.shape[2]
+        N, Do, Ho, Wo = head["out_dims"]
+        dhead = pool.get((N, Do, Ho, Wo, hw), dt)
+        a = (ptr(self.dpred_in), ptr(dhead), dtc, N, head["cw"].cout, Do * Ho * Wo, hw)
+        emit(lambda s, a=a: L.rho_pack_input(*a, s), "pack")
+        G[key(head["y2"])] = dhead
+        written.add(key(head["y2"]))
+
+        for node in reversed(self.nodes):
+            if node["k"] == "attn":
+                dao = G.get(key(node["ao"]))
+                N, T, Cc = node["N"], node["T"], node["C"]
+                dqkv = pool.get(tuple(node["qk"].shape[:4]) + (3 * Cc,), dt)   # = dY of the qkv projection
+                delta = pool.get((N, node["heads"], T), torch.float32)
+                a = (ptr(node["qk"]), ptr(node["vt"]), ptr(node["ao"]), ptr(dao), ptr(node["lse"]), ptr(delta), dqkv.data_ptr(), 3 * Cc,
+                     dqkv.data_ptr() + 2 * Cc * esz, 3 * Cc, dtc, N, T, node["heads"], Cc // node["heads"])
+                emit(lambda s, a=a: L.rho_attention_bwd(*a, s), "attention_bwd", flops=14.0 * N * T * T * Cc)
+                G[key(node["qk"])] = dqkv
+                written.add(key(node["qk"]))
+                pool.put(delta)
+                pool.put(G.pop(key(node["ao"])))
+                continue
+            cw = node["cw"]
+            out_t = node["y"] if node["y"] is not None else node["y2"]
+            dY = G.get(key(out_t))
+            if dY is None:
+                raise hip.RhoHipError("internal: missing output gradient in backward plan")
+            dyw = dY.shape[-1]
+            # residual input of the epilogue: alias (first contribution) or accumulate
+            if node["res"] is not None:
+                rk = key(node["res"])
+                if rk not in G:
+                    G[rk] = dY
+                    written.add(rk)
+                else:
+                    a = (ptr(G[rk]), ptr(dY), dtc, dY.numel())
+                    emit(lambda s, a=a: L.rho_add_inplace(*a, s), "add", nbytes=3.0 * esz * dY.numel())
+            bias_and_wgrad(node, dY, dyw)
+            if not node["stem"]:
+                dgrad(node, dY, dyw)
+            # the output gradient is dead now unless a residual aliased it
+            aliased = node["res"] is not None and G.get(key(node["res"])) is dY
+            G.pop(key(out_t), None)
+            if not aliased:
+                pool.put(dY)
+            ps = [cw.weight, cw.bias_param]
+            if node["pre"] is not None:
+                ps += [node["pre"]["norm"].weight, node["pre"]["norm"].bias]
+            self.bwd_marks.append((len(bw), ps))
+
+        # ---- embedding path (needs the FiLM gradients of every block)
+        e = 4 * eng.mc
+        first = True
+        emb_params: List[nn.Parameter] = []
+        for blk in eng._film_blocks:
+            lin = blk.emb_layers[1]
+            off = eng._film_off[id(blk)]
+            O = lin.weight.shape[0]
+            dptr = self.dfilm.data_ptr() + 4 * off
+            emit(lambda s, lin=lin, dptr=dptr, O=O, first=first: L.rho_linear_bwd(
+                dptr, film_stride, ptr(self.emb), ptr(lin.weight), pgrad(lin.weight), pgrad(lin.bias), ptr(self.demb), B, e, O, 1, 1,
+                0 if first else 1, s), "linear_bwd", flops=4.0 * B * e * O)
+            first = False
+            emb_params += [lin.weight, lin.bias]
+        te0, te2 = m.time_embed[0], m.time_embed[2]
+        emit(lambda s: L.rho_linear_bwd(ptr(self.demb), 0, ptr(self.emb_h), ptr(te2.weight), pgrad(te2.weight), pgrad(te2.bias),
+                                        ptr(self.demb_h), B, e, e, 1, 1, 0, s), "linear_bwd")
+        emit(lambda s: L.rho_linear_bwd(ptr(self.demb_h), 0, ptr(self.sin_in), ptr(te0.weight), pgrad(te0.weight), pgrad(te0.bias),
+                                        None, B, eng.mc, e, 0, 1, 0, s), "linear_bwd")
+        emb_params += [te2.weight, te2.bias, te0.weight, te0.bias]
+        self.bwd_marks.append((len(bw), emb_params))
+        self.pool_bytes = sum(t.numel() * t.element_size() for t in pool.all)
+
+    # ------------------------------------------------------------------ execution
     def run(self, x: Tensor, timesteps: Optional[Tensor], y: Optional[Tensor], t_scalar_dev: Optional[Tensor]) -> Tensor:
         eng = self.eng
         m = eng.model
@@ -357,6 +692,7 @@ class _Plan:
             hip.require_gpu(timesteps, "timesteps")
             ts = timesteps.to(torch.int64).contiguous()
             ops.embed_gather(eng.sin_table(1024), ts, self.B, out=self.sin_in)
+        self.cond_src = None
         if self.cond is not None:
             # label handling of unet_v2.py:702-719
             if y.dim() == 2 and tuple(y.shape) == tuple(self.emb.shape):
@@ -366,7 +702,10 @@ class _Plan:
                     assert y.shape == (x.shape[0],)
                 else:
                     assert y.shape[0] == self.emb.shape[0]
-                self.cond.copy_(m.cond_fn(y))
+                with (torch.enable_grad() if self.train else torch.no_grad()):
+                    c = m.cond_fn(y)          # a few embedding lookups on [B, k] labels (host-logic sized)
+                self.cond_src = c if (self.train and c.requires_grad) else None
+                self.cond.copy_(c.detach())
         s = hip.stream()
         for op in self.ops:
             rc = op(s)
@@ -374,15 +713,36 @@ class _Plan:
                 check(rc, "UNet plan launch")
         return self.out
 
-    def profile(self, repeats: int = 3) -> List[dict]:
-        """Replay the plan with a HIP event pair around every launch (events recorded on the stream
-        the kernels are launched on) and return per-launch dicts {kind, flops, bytes, ms} (ms = mean over repeats).
-        Inputs are whatever the buffers currently hold."""
+    def run_backward(self, dpred: Tensor, on_ready=None) -> None:
+        eng = self.eng
+        for p_ in eng.model.parameters():
+            if p_.grad is None:
+                p_.grad = torch.zeros_like(p_)
+        self.dpred_in.copy_(dpred.reshape(self.dpred_in.shape))
         s = hip.stream()
-        tot = [0.0] * len(self.ops)
+        marks = {i: ps for i, ps in self.bwd_marks}
+        for i, op in enumerate(self.bwd):
+            rc = op(s)
+            if rc != 0:
+                check(rc, "UNet backward plan launch")
+            if on_ready is not None and (i + 1) in marks:
+                on_ready(marks[i + 1])
+        if self.cond_src is not None:
+            with torch.enable_grad():
+                self.cond_src.backward(self.demb)      # MultiEmbeddings tables (tiny scatter-add)
+        if on_ready is not None:
+            on_ready([])
+
+    def profile(self, repeats: int = 3, backward: bool = False) -> List[dict]:
+        """Replay the plan with a HIP event pair around every launch (events recorded on the stream the
+        kernels are launched on) and return per-launch dicts {kind, flops, bytes, ms} (ms = mean over
+        repeats).  Inputs are whatever the buffers currently hold."""
+        s = hip.stream()
+        lst, infos = (self.bwd, self.bwd_info) if backward else (self.ops, self.info)
+        tot = [0.0] * len(lst)
         for _ in range(repeats):
-            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in self.ops]
-            for op, (e0, e1) in zip(self.ops, evs):
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in lst]
+            for op, (e0, e1) in zip(lst, evs):
                 e0.record()
                 rc = op(s)
                 e1.record()
@@ -391,4 +751,4 @@ class _Plan:
             torch.cuda.synchronize()
             for i, (e0, e1) in enumerate(evs):
                 tot[i] += e0.elapsed_time(e1)
-        return [dict(info, ms=tot[i] / repeats) for i, info in enumerate(self.info)]
+        return [dict(info, ms=tot[i] / repeats) for i, info in enumerate(infos)]

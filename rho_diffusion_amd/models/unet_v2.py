@@ -259,5 +259,10 @@ class UNet(nn.Module):
         """x [N, C, *spatial] float32, timesteps [N] int64, y labels (see unet_v2.py:685-732)."""
         assert (y is not None) == (self.num_classes is not None), \
             "must specify y if and only if the model is class-conditional"
+        if torch.is_grad_enabled() and self.training:
+            anchor = next((p for p in self.parameters() if p.requires_grad), None)
+            if anchor is not None:
+                from ..autograd import UNetFunction
+                return UNetFunction.apply(x, anchor, self.engine(), timesteps, y, getattr(self, "grad_hooks", None))
         # the engine returns its (reused) output buffer; hand the caller a tensor of its own
         return self.engine().forward(x, timesteps, y).clone()

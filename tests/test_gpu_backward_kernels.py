@@ -106,7 +106,8 @@ def test_conv_dgrad_and_wgrad(ops, dtype, case):
     xin1, xin2 = x1cl, x2cl
     if up:
         xin1 = ops.upsample2x(x1cl, up_hw)
-    dfw = ops.make_conv_desc(xin1, xin2, wf, torch.zeros(wf.shape[1], device=DEV), kernel=kernel, cout=cout, split=cout,
+    zbw = torch.zeros(wf.shape[1], device=DEV)
+    dfw = ops.make_conv_desc(xin1, xin2, wf, zbw, kernel=kernel, cout=cout, split=cout,
                              y=dycl, y2=None, stride_hw=stride_hw)
     dwbuf = torch.zeros(wf.shape[0], wf.shape[1], wf.shape[2], dtype=torch.float32, device=DEV)
     ops.conv_wgrad(dfw, dycl, dwbuf)
@@ -130,8 +131,10 @@ def test_conv_wgrad_with_prologue(ops, dtype):
     y.backward(dy)
     wf = ops.prep_conv_weight(w.detach().to(DEV), dtype)
     dycl = to_cl(dy, dtype)
-    d = ops.make_conv_desc(to_cl(x, dtype), None, wf, torch.zeros(wf.shape[1], device=DEV), kernel=(3, 3, 3), cout=cout, split=cout,
-                           y=dycl, y2=None, pre_a=a.to(DEV), pre_b=b.to(DEV), pre_silu=True)
+    # descriptors hold raw pointers: keep every tensor alive for as long as the descriptor is used
+    xcl, zb, a_d, b_d = to_cl(x, dtype), torch.zeros(wf.shape[1], device=DEV), a.to(DEV), b.to(DEV)
+    d = ops.make_conv_desc(xcl, None, wf, zb, kernel=(3, 3, 3), cout=cout, split=cout,
+                           y=dycl, y2=None, pre_a=a_d, pre_b=b_d, pre_silu=True)
     dwbuf = torch.zeros(tuple(wf.shape), dtype=torch.float32, device=DEV)
     ops.conv_wgrad(d, dycl, dwbuf)
     grad = torch.zeros(tuple(w.shape), device=DEV)
@@ -250,9 +253,9 @@ def test_attention_backward(ops, dtype, B, T, heads, ch):
     ref_lse = torch.logsumexp(logits, dim=-1) / math.log(2.0)
     assert rel_l2(lse, ref_lse) < (1e-5 if dtype == torch.float32 else 5e-3)
     docl = dout.permute(0, 2, 1).contiguous().to(DEV).to(dtype)
-    dqk, dv = ops.attention_bwd(qk, vt, o, docl, lse, heads)
+    dqkv = ops.attention_bwd(qk, vt, o, docl, lse, heads)
     t = tolb(dtype, f32=5e-5, bf16=2.5e-2)
-    dqk = dqk.float().cpu().permute(0, 2, 1)
-    assert rel_l2(dqk[:, :C], q.grad) < t, "dq"
-    assert rel_l2(dqk[:, C:], k.grad) < t, "dk"
-    assert rel_l2(dv.float().cpu().permute(0, 2, 1), v.grad) < t, "dv"
+    dqkv = dqkv.float().cpu().permute(0, 2, 1)
+    assert rel_l2(dqkv[:, :C], q.grad) < t, "dq"
+    assert rel_l2(dqkv[:, C:2 * C], k.grad) < t, "dk"
+    assert rel_l2(dqkv[:, 2 * C:], v.grad) < t, "dv"
