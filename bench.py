@@ -32,7 +32,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", choices=["sample", "train"], default="sample")
+    ap.add_argument("--mode", choices=["sample", "train", "both"], default="both",
+                    help="sample: denoising steps/s; train: training samples/s; both (default): `value` is the denoising rate, "
+                         "the training rate rides along in the same JSON line")
+    ap.add_argument("--train-steps", type=int, default=None, help="timed training steps in --mode both (default: --steps)")
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[2]: 32)")
     ap.add_argument("--grid", type=int, default=64)
     ap.add_argument("--dims", type=int, default=3)
@@ -93,6 +96,42 @@ def cpu_baseline(kw, ddpm, args):
                       f"scaled x{args.batch} in time; fp32 oracle (oracle/ref_torch.py)"}
 
 
+def by_kind(prof):
+    acc = {}
+    for p in prof:
+        k = acc.setdefault(p["kind"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+        k["ms"] += p["ms"]; k["flops"] += p["flops"]; k["bytes"] += p["bytes"]; k["launches"] += 1
+    return acc
+
+
+def roofline_of(plan, args):
+    """Dominant kernel = the 3x3x3 conv: achieved = algorithmic FLOPs of its launches in one step / their summed
+    durations, each launch bracketed by HIP events on the launch stream (plan.profile)."""
+    prof = plan.profile(repeats=3)
+    conv3 = [p for p in prof if p["kind"] == "conv3"]
+    fl = sum(p["flops"] for p in conv3)
+    ms = sum(p["ms"] for p in conv3)
+    kinds = by_kind(prof)
+    if args.dump_ops:
+        with open(args.dump_ops, "w") as f:
+            for i, p_ in enumerate(prof):
+                tf = p_["flops"] / (p_["ms"] * 1e-3) / 1e12 if p_["ms"] > 0 else 0.0
+                gb = p_["bytes"] / (p_["ms"] * 1e-3) / 1e9 if p_["ms"] > 0 else 0.0
+                f.write(f"{i:4d} {p_['kind']:12s} ms={p_['ms']:8.3f} TF/s={tf:8.1f} GB/s={gb:8.1f} "
+                        f"cin={p_.get('cin', '')} cout={p_.get('cout', '')} taps={p_.get('taps', '')} pos={p_.get('positions', '')}\n")
+    peak = MFMA_PEAK_TFLOPS[args.dtype]
+    achieved = fl / (ms * 1e-3) / 1e12
+    return {
+        "bound": "mfma", "kernel": "k_conv (3x3x3 implicit GEMM, LDS halo tile)", "achieved": achieved, "peak": peak,
+        "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+        "launches_per_step": len(conv3), "avg_launch_ms": ms / max(1, len(conv3)),
+        "algorithmic_flops_per_step": fl, "kernel_ms_per_step": ms, "all_kernels_ms_per_step": sum(p["ms"] for p in prof),
+        "by_kind_ms": {k: round(v["ms"], 3) for k, v in kinds.items()},
+        "hbm_kernels_GBps": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in kinds.items()
+                             if k in ("gn_partial", "pack") and v["ms"] > 0},
+    }
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,79 +158,106 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.mode == "sample":
+    results = {}
+    roofline = None
+    if world > 1:   # warm-up collective (cf. xpu.py:374-375), not part of the sampling data path
+        w = torch.ones(8, device=device)
+        dist.all_reduce(w)
+
+    def timed(step_fn, steps, warmup):
+        for _ in range(warmup):
+            step_fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    if args.mode in ("sample", "both"):
         x_t = ddpm.noise(torch.empty(shape, device=device))
         z = torch.empty(shape, dtype=torch.float32, device=device)
         t_dev = torch.full((1,), 999, dtype=torch.int32, device=device)
         off_dev = torch.full((1,), 1 << 32, dtype=torch.int64, device=device)
         n_elem = x_t.numel()
 
-        def step():
+        def sample_step():
             ops.philox_normal(z, ddpm.noise_seed, 0, offset_dev=off_dev)
             pred = engine.forward(x_t, None, None, t_scalar_dev=t_dev)
             ops.p_sample_step(x_t, pred, z, tables["coef"], t_dev)
             ops.step_advance(t_dev, off_dev, (n_elem + 3) // 4)
-        metric, unit = "denoising_steps_per_sec", "steps/s"
-        units_per_step = 1.0
-    else:
-        raise SystemExit("--mode train: backward kernels are not built yet (DESIGN.md, 'next')")
 
-    if world > 1:   # warm-up collective (cf. xpu.py:374-375), not part of the data path
-        w = torch.ones(8, device=device)
-        dist.all_reduce(w)
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    assert torch.isfinite(x_t).all(), "non-finite state after the timed steps"
+        dt = timed(sample_step, args.steps, args.warmup)
+        assert torch.isfinite(x_t).all(), "non-finite state after the timed steps"
+        results["sample"] = dict(dt=dt, steps=args.steps)
+        if rank == 0 and not args.no_roofline:
+            roofline = roofline_of(next(iter(engine._plans.values())), args)
+
+    if args.mode in ("train", "both"):
+        # synthetic spherical-harmonics density fields (rho_diffusion/data/synthetic.py:45-124), pool generated once
+        from oracle.ref_torch import spherical_harmonic_field   # input generator only (scipy on the host), not timed
+        import random
+        rng = random.Random(777 + rank)
+        pool = []
+        for _ in range(8):
+            l = rng.randint(0, 5)
+            pool.append(spherical_harmonic_field(l, rng.randint(-l, l), args.grid, args.dims))
+        data = torch.stack([pool[i % len(pool)] for i in range(B)]).to(device).contiguous()
+        from rho_diffusion_amd.trainer import DPTrainer
+        trainer = DPTrainer(ddpm, lr=1e-4)
+        last = {}
+
+        def train_step():
+            last["loss"] = trainer.step(data)
+
+        tsteps = args.train_steps or args.steps
+        dt = timed(train_step, tsteps, max(1, args.warmup))
+        assert torch.isfinite(last["loss"]).all(), "non-finite training loss"
+        results["train"] = dict(dt=dt, steps=tsteps, loss=float(last["loss"]))
+        if rank == 0 and not args.no_roofline:
+            tp = engine._last_train_plan
+            fk, bk = by_kind(tp.profile(repeats=1)), by_kind(tp.profile(repeats=1, backward=True))
+            results["train"]["breakdown"] = {"fwd": {k: round(v["ms"], 2) for k, v in fk.items()},
+                                             "bwd": {k: round(v["ms"], 2) for k, v in bk.items()},
+                                             "bwd_TFLOPs": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in bk.items()
+                                                            if v["flops"] > 0 and v["ms"] > 0}}
+            if roofline is None:
+                roofline = roofline_of(tp, args)
+
+    if "sample" in results:
+        r = results["sample"]
+        metric, unit, value, steps, dt = "denoising_steps_per_sec", "steps/s", world * r["steps"] / r["dt"], r["steps"], r["dt"]
+    else:
+        r = results["train"]
+        metric, unit, value, steps, dt = "training_samples_per_sec", "samples/s", world * B * r["steps"] / r["dt"], r["steps"], r["dt"]
 
     out = {
-        "metric": metric, "value": world * units_per_step * args.steps / dt, "unit": unit, "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+        "metric": metric, "value": value, "unit": unit, "n_gpus": world,
+        "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"DDPM reverse step, UNetv2 {args.dims}D {args.grid}^{args.dims} mc={args.mc} "
                                f"(BASELINE configs[2]), batch {B}/GPU, LinearSchedule(1000,1e-3,0.02)",
-                   "global_batch": B * world, "sample_steps_per_sec": world * B * args.steps / dt,
-                   "parallelism": f"independent samples x{world} (no data-path collective)"},
+                   "global_batch": B * world,
+                   "parallelism": f"independent samples x{world} (sampling: no data-path collective; training: DP gradient "
+                                  f"all-reduce over RCCL, overlapped with backward)"},
     }
+    if "sample" in results:
+        out["config"]["sample_steps_per_sec"] = world * B * results["sample"]["steps"] / results["sample"]["dt"]
+    if "train" in results:
+        r = results["train"]
+        out["training"] = {"metric": "training_samples_per_sec", "value": world * B * r["steps"] / r["dt"], "unit": "samples/s",
+                           "steps": r["steps"], "ms_per_step": 1e3 * r["dt"] / r["steps"], "loss": r["loss"],
+                           "step": "q_sample + UNetv2 fwd + MSE + bwd + " + ("RCCL grad all-reduce + " if world > 1 else "") + "fused AdamW"}
 
-    if rank == 0 and not args.no_roofline:
-        plan = next(iter(engine._plans.values()))
-        prof = plan.profile(repeats=3)
-        conv3 = [p for p in prof if p["kind"] == "conv3"]
-        fl = sum(p["flops"] for p in conv3)
-        ms = sum(p["ms"] for p in conv3)
-        tot_ms = sum(p["ms"] for p in prof)
-        by_kind = {}
-        for p in prof:
-            k = by_kind.setdefault(p["kind"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
-            k["ms"] += p["ms"]; k["flops"] += p["flops"]; k["bytes"] += p["bytes"]; k["launches"] += 1
-        if args.dump_ops:
-            with open(args.dump_ops, "w") as f:
-                for i, p_ in enumerate(prof):
-                    tf = p_["flops"] / (p_["ms"] * 1e-3) / 1e12 if p_["ms"] > 0 else 0.0
-                    gb = p_["bytes"] / (p_["ms"] * 1e-3) / 1e9 if p_["ms"] > 0 else 0.0
-                    f.write(f"{i:4d} {p_['kind']:12s} ms={p_['ms']:8.3f} TF/s={tf:8.1f} GB/s={gb:8.1f} "
-                            f"cin={p_.get('cin', '')} cout={p_.get('cout', '')} taps={p_.get('taps', '')} pos={p_.get('positions', '')}\n")
-        peak = MFMA_PEAK_TFLOPS[args.dtype]
-        achieved = fl / (ms * 1e-3) / 1e12
-        out["roofline"] = {
-            "bound": "mfma", "kernel": "k_conv (3x3x3 implicit GEMM, LDS halo tile)", "achieved": achieved, "peak": peak,
-            "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
-            "launches_per_step": len(conv3), "avg_launch_ms": ms / max(1, len(conv3)),
-            "algorithmic_flops_per_step": fl, "kernel_ms_per_step": ms, "all_kernels_ms_per_step": tot_ms,
-            "by_kind_ms": {k: round(v["ms"], 3) for k, v in by_kind.items()},
-            "hbm_kernels_GBps": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in by_kind.items()
-                                 if k in ("gn_partial", "pack") and v["ms"] > 0},
-        }
+    if roofline is not None:
+        out["roofline"] = roofline
+    if "train" in results and results["train"].get("breakdown"):
+        out["training"]["by_kind_ms"] = results["train"]["breakdown"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(kw, ddpm, args)
     if rank == 0:

@@ -10,16 +10,21 @@ from .engine import ops
 
 
 class HipAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, arena_order=None):
+        """``arena_order``: optional parameter order for the flat arena (``UNetEngine.param_order()``), so
+        that the gradients that become final together during backward are adjacent in memory."""
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self._arena = None
+        self._arena_order = {id(p): i for i, p in enumerate(arena_order)} if arena_order is not None else None
 
     def _build_arena(self):
         """Re-home every parameter into one contiguous fp32 arena (views keep the module API intact)."""
         self._arena = []
         for group in self.param_groups:
             ps = [p for p in group["params"] if p.requires_grad]
+            if self._arena_order is not None:
+                ps.sort(key=lambda p: self._arena_order.get(id(p), 1 << 30))
             n = sum(p.numel() for p in ps)
             dev = ps[0].device
             flat = torch.empty(n, dtype=torch.float32, device=dev)
@@ -32,6 +37,11 @@ class HipAdamW(torch.optim.Optimizer):
                 p.grad = grad[off:off + k].view_as(p)
                 off += k
             self._arena.append(dict(flat=flat, grad=grad, m=torch.zeros_like(flat), v=torch.zeros_like(flat), step=0, params=ps))
+
+    def build_arena(self):
+        if self._arena is None:
+            self._build_arena()
+        return self._arena
 
     @property
     def flat_grads(self):
