@@ -148,66 +148,105 @@ __global__ __launch_bounds__(256) void k_conv(const ConvK p) {
     const char* const w_src0 = p.w + ((size_t)co0 + (tid >> 2)) * wrow_bytes + piece * 16;
     const size_t w_tap_stride = (size_t)p.coutp * wrow_bytes;
     const int w_dst0 = (tid >> 2) * PITCH + piece * 16;
-    uint4 wreg0 = make_uint4(0u, 0u, 0u, 0u), wreg1 = make_uint4(0u, 0u, 0u, 0u);
-#define RHO_LOAD_W(ck_, tap_)                                                                        \
+    // weights are fetched PD taps ahead of their use (L2 latency ~1.5k cycles vs ~0.5k cycles of MFMA per tap):
+    // a register ring of PD sets, set (step % PD) holds step's tile; the LDS ring stays 2 deep.
+    constexpr int PD = (NT % 3 == 0) ? 3 : 1;
+    uint4 wq0[PD], wq1[PD];
+#pragma unroll
+    for (int i = 0; i < PD; ++i) wq0[i] = wq1[i] = make_uint4(0u, 0u, 0u, 0u);
+#define RHO_LOAD_W(set_, ck_, tap_)                                                                   \
     do {                                                                                             \
         const char* ws_ = w_src0 + (size_t)(tap_) * w_tap_stride + (size_t)(ck_) * 64;               \
-        if (w_active) wreg0 = *reinterpret_cast<const uint4*>(ws_);                                  \
-        if constexpr (WROWS == 2) wreg1 = *reinterpret_cast<const uint4*>(ws_ + 64 * wrow_bytes);    \
+        if (w_active) wq0[set_] = *reinterpret_cast<const uint4*>(ws_);                              \
+        if constexpr (WROWS == 2) wq1[set_] = *reinterpret_cast<const uint4*>(ws_ + 64 * wrow_bytes); \
     } while (0)
-#define RHO_STORE_W(buf_)                                                                            \
+#define RHO_STORE_W(buf_, set_)                                                                      \
     do {                                                                                             \
         char* wd_ = wbuf + (size_t)(buf_) * BM * PITCH + w_dst0;                                     \
-        if (w_active) *reinterpret_cast<uint4*>(wd_) = wreg0;                                        \
-        if constexpr (WROWS == 2) *reinterpret_cast<uint4*>(wd_ + 64 * PITCH) = wreg1;               \
+        if (w_active) *reinterpret_cast<uint4*>(wd_) = wq0[set_];                                    \
+        if constexpr (WROWS == 2) *reinterpret_cast<uint4*>(wd_ + 64 * PITCH) = wq1[set_];           \
     } while (0)
 
-    RHO_LOAD_W(0, 0);
-    RHO_STORE_W(0);
+    // prologue: steps 0 .. PD-1 in flight, step 0 landed in LDS slot 0
+#pragma unroll
+    for (int i = 0; i < PD; ++i) RHO_LOAD_W(i, 0, i % NT);     // PD <= NT always
+    RHO_STORE_W(0, 0);
     int cur = 0;
+
+    // Halo staging.  HPF (one workgroup per CU, nothing else to hide behind): the NEXT chunk's global loads are
+    // issued into registers while the last taps of the current chunk run on the matrix cores, and only the
+    // prologue + LDS write happens between chunks (issue-early / write-late).  Otherwise (>= 2 workgroups per CU
+    // overlap each other) load and write in small batches to keep the register footprint down.
+    constexpr bool HPF = (BM >= 128) && (MAXP <= 10);
+    constexpr int TPF = (NT > 6) ? NT - 6 : 0;        // tap at which the next chunk's loads are issued
+    uint4 hv[HPF ? MAXP : 1];
+    auto halo_src = [&](int ck_, const char*& src, int& cs, int& csrc) {
+        const int c = ck_ * CK;
+        if (c < p.c1) { src = p.x1; cs = p.c1; csrc = c; } else { src = p.x2; cs = p.c2; csrc = c - p.c1; }
+    };
+#define RHO_HALO_LOAD(ck_)                                                                                         \
+    do {                                                                                                          \
+        const char* src_; int cs_, csrc_;                                                                         \
+        halo_src(ck_, src_, cs_, csrc_);                                                                          \
+        /* branch-free (padding lanes read position 0 and are zeroed at write time): loads under an exec mask */  \
+        /* are invisible to the compiler's counted vmcnt waits, which would then drain them immediately        */  \
+        _Pragma("unroll") for (int i = 0; i < MAXP; ++i) {                                                        \
+            const int ps_ = spos[i] > 0 ? spos[i] : 0;                                                            \
+            hv[i] = *reinterpret_cast<const uint4*>(src_ + ((size_t)ps_ * cs_ + csrc_) * sizeof(T) + piece * 16); \
+        }                                                                                                         \
+    } while (0)
+    if constexpr (HPF) RHO_HALO_LOAD(0);
 
     for (int ck = 0; ck < nck; ++ck) {
         // ---- stage the halo tile of this channel chunk (previous chunk's reads are fenced by the
         //      barrier that closed its last tap)
         {
             const int c = ck * CK;
-            const char* src;
-            int cs, csrc;
-            if (c < p.c1) {
-                src = p.x1;
-                cs = p.c1;
-                csrc = c;
-            } else {
-                src = p.x2;
-                cs = p.c2;
-                csrc = c - p.c1;
-            }
-            constexpr int GB = (MAXP % 7 == 0) ? 7 : 5;  // loads in flight per batch (divides MAXP)
+            if constexpr (HPF) {
 #pragma unroll
-            for (int i0 = 0; i0 < MAXP; i0 += GB) {
-                uint4 v[GB];
-#pragma unroll
-                for (int q = 0; q < GB; ++q) {
-                    const int i = i0 + q;
-                    if (i < MAXP) {
-                        v[q] = make_uint4(0u, 0u, 0u, 0u);
-                        if (spos[i] >= 0)
-                            v[q] = *reinterpret_cast<const uint4*>(src + ((size_t)spos[i] * cs + csrc) * sizeof(T) + piece * 16);
+                for (int i = 0; i < MAXP; ++i) {
+                    if (spos[i] != -2) {
+                        uint4 u = spos[i] >= 0 ? hv[i] : make_uint4(0u, 0u, 0u, 0u);
+                        if (p.pre_a != nullptr && spos[i] >= 0) {
+                            const int smp = (KD == 3) ? n : ssmp[(KD == 3) ? 0 : i];
+                            const size_t co = (size_t)smp * p.cin + c + piece * PE;
+                            u = apply_pre<T>(u, p.pre_a + co, p.pre_b + co, p.pre_silu);
+                        }
+                        const int hp = (tid >> 2) + 64 * i;
+                        *reinterpret_cast<uint4*>(halo + hp * PITCH + piece * 16) = u;
                     }
                 }
+            } else {
+                const char* src;
+                int cs, csrc;
+                halo_src(ck, src, cs, csrc);
+                constexpr int GB = (MAXP % 7 == 0) ? 7 : 5;  // loads in flight per batch (divides MAXP)
 #pragma unroll
-                for (int q = 0; q < GB; ++q) {
-                    const int i = i0 + q;
-                    if (i < MAXP) {
-                        if (spos[i] != -2) {
-                            uint4 u = v[q];
-                            if (p.pre_a != nullptr && spos[i] >= 0) {
-                                const int smp = (KD == 3) ? n : ssmp[(KD == 3) ? 0 : i];
-                                const size_t co = (size_t)smp * p.cin + c + piece * PE;
-                                u = apply_pre<T>(u, p.pre_a + co, p.pre_b + co, p.pre_silu);
+                for (int i0 = 0; i0 < MAXP; i0 += GB) {
+                    uint4 v[GB];
+#pragma unroll
+                    for (int q = 0; q < GB; ++q) {
+                        const int i = i0 + q;
+                        if (i < MAXP) {
+                            v[q] = make_uint4(0u, 0u, 0u, 0u);
+                            if (spos[i] >= 0)
+                                v[q] = *reinterpret_cast<const uint4*>(src + ((size_t)spos[i] * cs + csrc) * sizeof(T) + piece * 16);
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < GB; ++q) {
+                        const int i = i0 + q;
+                        if (i < MAXP) {
+                            if (spos[i] != -2) {
+                                uint4 u = v[q];
+                                if (p.pre_a != nullptr && spos[i] >= 0) {
+                                    const int smp = (KD == 3) ? n : ssmp[(KD == 3) ? 0 : i];
+                                    const size_t co = (size_t)smp * p.cin + c + piece * PE;
+                                    u = apply_pre<T>(u, p.pre_a + co, p.pre_b + co, p.pre_silu);
+                                }
+                                const int hp = (tid >> 2) + 64 * i;
+                                *reinterpret_cast<uint4*>(halo + hp * PITCH + piece * 16) = u;
                             }
-                            const int hp = (tid >> 2) + 64 * i;
-                            *reinterpret_cast<uint4*>(halo + hp * PITCH + piece * 16) = u;
                         }
                     }
                 }
@@ -224,10 +263,24 @@ __global__ __launch_bounds__(256) void k_conv(const ConvK p) {
                 for (int kw = 0; kw < KW; ++kw) {
                     const int tap = (kd * KH + kh) * KW + kw;
                     const bool has_next = !(ck == nck - 1 && tap == NT - 1);
-                    if (has_next) {
-                        const int ntap = (tap == NT - 1) ? 0 : tap + 1;
-                        const int nckk = (tap == NT - 1) ? ck + 1 : ck;
-                        RHO_LOAD_W(nckk, ntap);
+                    // step q = ck*NT + tap: its register set (tap % PD) went to LDS one step ago -> refill it with
+                    // step q + PD now, so the fetch has PD taps of MFMA work to hide under; at the end of this step
+                    // step q + 1 (fetched PD - 1 steps ago) is handed to the other LDS slot.
+                    // (unconditional: past the end it re-reads the last chunk's tile, so that the number of loads in
+                    //  flight is static and the compiler can wait with a counted vmcnt instead of draining to 0)
+                    {
+                        const int ntap = (tap + PD < NT) ? tap + PD : tap + PD - NT;
+                        const int nckk = (tap + PD < NT) ? ck : min(ck + 1, nck - 1);
+                        RHO_LOAD_W(tap % PD, nckk, ntap);
+                    }
+                    // next chunk's halo: issued AFTER this tap's weight fetch (vmcnt retires in order, so the counted
+                    // waits for the next PD-1 taps' weights do not drain these loads) and unconditionally (static count)
+                    if constexpr (HPF) {
+                        if (tap == TPF) {
+                            __builtin_amdgcn_sched_barrier(0);     // keep the halo loads younger than the weight fetch above
+                            RHO_HALO_LOAD(min(ck + 1, nck - 1));
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                     const char* wcur = wbuf + (size_t)cur * BM * PITCH + a_off;
                     const int dtap = kd * p.IH * p.IW * PITCH;
@@ -244,7 +297,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvK p) {
                             mma_step<T>(a, b1, acc[mi][1]);
                         }
                     }
-                    if (has_next) RHO_STORE_W(cur ^ 1);
+                    if (has_next) RHO_STORE_W(cur ^ 1, (tap + 1) % PD);
                     __syncthreads();
                     cur ^= 1;
                 }
@@ -254,6 +307,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvK p) {
 
 #undef RHO_LOAD_W
 #undef RHO_STORE_W
+#undef RHO_HALO_LOAD
     // ---- epilogue: lane holds, for position column (lane&31) of tile j, channels
     //      co0 + 32*mi + 8*rg + 4*half + {0,1,2,3}  in acc[mi][j][4*rg + {0..3}]
     const bool cl_region = (co0 < p.split);
