@@ -28,7 +28,11 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with the hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each) instead of an IEEE
+// division sequence: this sits in the conv loaders, where every VALU instruction competes with the MFMA issue.
+__device__ __forceinline__ float silu_f(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

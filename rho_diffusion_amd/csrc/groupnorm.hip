@@ -185,7 +185,7 @@ extern "C" int rho_gn_finalize(const float* partials, int64_t n, int64_t c, int6
 // forward statistics) give every parameter / FiLM gradient and the group means, so pass 2 is a pure
 // elementwise   dx = A[n,c]*gq + P[n,grp] + Q[n,grp]*x .
 __device__ __forceinline__ float dsilu_f(float u) {
-    const float s = 1.0f / (1.0f + __expf(-u));
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * u));
     return s * (1.0f + u * (1.0f - s));
 }
 
