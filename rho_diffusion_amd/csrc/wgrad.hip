@@ -99,7 +99,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     for (int ti = 0; ti < TPW; ++ti) {
         const int tap = TAPSPLIT ? wave + 4 * ti : ti;
         tap_of[ti] = tap;
-        const int kd = tap / (KH * KW), kh = (tap / KW) % KH, kw = tap % KW;
+        // a slot past the last tap (27 = 4*7 - 1) still runs, on the last tap's window, and is not flushed:
+        // branch-free inner loop (an exec-masked branch per tap pair serialises LDS latency with the MFMAs)
+        const int tc = tap < NT ? tap : NT - 1;
+        const int kd = tc / (KH * KW), kh = (tc / KW) % KH, kw = tc % KW;
         tapoff[ti] = ((kd * p.IH + kh) * p.IW + kw) * PITCH;
     }
 
@@ -117,59 +120,81 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
 
     const int tile0 = blockIdx.x * p.tiles_per_block;
     const int tile1 = min(tile0 + p.tiles_per_block, p.tiles_total);
-    for (int tl = tile0; tl < tile1; ++tl) {
+
+    // Staging is software-pipelined across tiles: the global loads of tile t+1 (branch-free, padding lanes read a
+    // clamped address and are zeroed later, so all of them are in flight together and visible to the counted
+    // vmcnt) are issued before the MFMA phase of tile t and consumed after it.
+    uint4 xv[MAXP], dv[8];
+    int xpos[MAXP];          // global input position of each halo slot (-1 = zero padding) of the tile in flight
+    unsigned dok = 0;        // validity bits of the 8 dY rows of the tile in flight
+    int n_cur = 0;
+    const int dpiece = tid & 7;
+    const bool dch_ok = (co0 + dpiece * PE) < p.dyw;
+
+    auto issue = [&](int tl) {
         int t = tl;
         const int tw_i = t % p.tiles_w; t /= p.tiles_w;
         const int th_i = t % p.tiles_h; t /= p.tiles_h;
         const int td_i = t % p.tiles_d;
         const int n = t / p.tiles_d;
+        n_cur = n;
         const int od0 = td_i * p.TD, oh0 = th_i * p.TH, ow0 = tw_i * p.TW;
         const int gd_base = od0 - (KD / 2), gh_base = oh0 * p.sh - (KH / 2), gw_base = ow0 * p.sw - (KW / 2);
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int id = sdec[i] >> 20, ih = (sdec[i] >> 10) & 1023, iw = sdec[i] & 1023;
+            const int gd = gd_base + id, gh = gh_base + ih, gw = gw_base + iw;
+            const bool ok = sdec[i] >= 0 && gd >= 0 && gd < p.D && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
+            const int pos = ok ? ((n * p.D + gd) * p.H + gh) * p.W + gw : 0;
+            xpos[i] = ok ? pos : -1;
+            xv[i] = *reinterpret_cast<const uint4*>(src + ((size_t)pos * cs + csrc) * sizeof(T) + piece * 16);
+        }
+        dok = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = (tid >> 3) + 32 * i;
+            const int pw = row & (p.TW - 1), ph = (row >> p.lgTW) & (p.TH - 1), pd = row >> (p.lgTW + p.lgTH);
+            const int od = od0 + pd, oh = oh0 + ph, ow = ow0 + pw;
+            const bool ok = od < p.Do && oh < p.Ho && ow < p.Wo && dch_ok;
+            const size_t L = ok ? ((((size_t)n * p.Do + od) * p.Ho + oh) * p.Wo + ow) : 0;
+            dok |= (ok ? 1u : 0u) << i;
+            dv[i] = *reinterpret_cast<const uint4*>(p.dy + (L * p.dyw + (dch_ok ? co0 + dpiece * PE : 0)) * sizeof(T));
+        }
+    };
 
+    constexpr bool PF = (MAXP <= 10);      // big-halo (strided) variant: no cross-tile prefetch, it would spill
+    if (PF && tile0 < tile1) issue(tile0);
+    for (int tl = tile0; tl < tile1; ++tl) {
+        if constexpr (!PF) issue(tl);
         __syncthreads();   // previous tile's fragments consumed
-        // ---- input halo chunk (prologue applied, zero padding after the activation)
+        // ---- input halo chunk (prologue applied, zero padding after the activation) and dY tile -> LDS
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
             if (sdec[i] >= 0) {
-                const int id = sdec[i] >> 20, ih = (sdec[i] >> 10) & 1023, iw = sdec[i] & 1023;
-                const int gd = gd_base + id, gh = gh_base + ih, gw = gw_base + iw;
-                uint4 u = make_uint4(0u, 0u, 0u, 0u);
-                if (gd >= 0 && gd < p.D && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W) {
-                    const int pos = ((n * p.D + gd) * p.H + gh) * p.W + gw;
-                    u = *reinterpret_cast<const uint4*>(src + ((size_t)pos * cs + csrc) * sizeof(T) + piece * 16);
-                    if (p.pre_a != nullptr) {
-                        const int smp = (KD == 3) ? n : (int)((unsigned)pos / (unsigned)p.S_in);
-                        const size_t co = (size_t)smp * p.cin + c + piece * PE;
-                        u = apply_pre<T>(u, p.pre_a + co, p.pre_b + co, p.pre_silu);
-                    }
+                uint4 u = xpos[i] >= 0 ? xv[i] : make_uint4(0u, 0u, 0u, 0u);
+                if (p.pre_a != nullptr && xpos[i] >= 0) {
+                    const int smp = (KD == 3) ? n_cur : (int)((unsigned)xpos[i] / (unsigned)p.S_in);
+                    const size_t co = (size_t)smp * p.cin + c + piece * PE;
+                    u = apply_pre<T>(u, p.pre_a + co, p.pre_b + co, p.pre_silu);
                 }
                 const int hp = (tid >> 2) + 64 * i;
                 *reinterpret_cast<uint4*>(halo + hp * PITCH + piece * 16) = u;
             }
         }
-        // ---- dY tile: 256 positions x 128 bytes
-        {
-            const int dpiece = tid & 7;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = (tid >> 3) + 32 * i;
-                const int pw = row & (p.TW - 1), ph = (row >> p.lgTW) & (p.TH - 1), pd = row >> (p.lgTW + p.lgTH);
-                const int od = od0 + pd, oh = oh0 + ph, ow = ow0 + pw;
-                uint4 u = make_uint4(0u, 0u, 0u, 0u);
-                const int ch = co0 + dpiece * PE;
-                if (od < p.Do && oh < p.Ho && ow < p.Wo && ch < p.dyw) {
-                    const size_t L = (((size_t)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
-                    u = *reinterpret_cast<const uint4*>(p.dy + (L * p.dyw + ch) * sizeof(T));
-                }
-                *reinterpret_cast<uint4*>(dyt + row * DY_PITCH + dpiece * 16) = u;
-            }
+        for (int i = 0; i < 8; ++i) {
+            const int row = (tid >> 3) + 32 * i;
+            const uint4 u = ((dok >> i) & 1u) ? dv[i] : make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(dyt + row * DY_PITCH + dpiece * 16) = u;
         }
         __syncthreads();
+        if constexpr (PF) issue(min(tl + 1, tile1 - 1));   // next tile's loads fly under this tile's MFMAs (last: harmless re-read)
 
         // ---- reduce this tile's positions
         if constexpr (IS_BF16) {
             const int ks0 = TAPSPLIT ? 0 : wave * 4;
             const int ks1 = TAPSPLIT ? 16 : wave * 4 + 4;
+#pragma unroll 2
             for (int ks = ks0; ks < ks1; ++ks) {
                 // k rows of this lane: position index 16*ks + 8*half' + 4*t + q with half' = grp>>1
                 int xr[2], ar[2];
@@ -185,11 +210,9 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
                 for (int mi = 0; mi < MT; ++mi) a[mi] = tr_frag(dyt, ar[0] + mi * 64, ar[1] + mi * 64);
 #pragma unroll
                 for (int ti = 0; ti < TPW; ++ti) {
-                    if (tap_of[ti] < NT) {
-                        const uint4 b = tr_frag(halo, xr[0] + tapoff[ti], xr[1] + tapoff[ti]);
+                    const uint4 b = tr_frag(halo, xr[0] + tapoff[ti], xr[1] + tapoff[ti]);
 #pragma unroll
-                        for (int mi = 0; mi < MT; ++mi) mma_step<T>(a[mi], b, acc[ti][mi]);
-                    }
+                    for (int mi = 0; mi < MT; ++mi) mma_step<T>(a[mi], b, acc[ti][mi]);
                 }
             }
         } else {
@@ -204,11 +227,9 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
                 const int xrow = ((pd * p.IH + ph * p.sh) * p.IW + pw * p.sw) * PITCH + (col & 15) * 4;
 #pragma unroll
                 for (int ti = 0; ti < TPW; ++ti) {
-                    if (tap_of[ti] < NT) {
-                        float bv = *reinterpret_cast<const float*>(halo + xrow + tapoff[ti]);
-                        bv = (col < 16) ? bv : 0.0f;
-                        acc[ti][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[ti][0], 0, 0, 0);
-                    }
+                    float bv = *reinterpret_cast<const float*>(halo + xrow + tapoff[ti]);
+                    bv = (col < 16) ? bv : 0.0f;
+                    acc[ti][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[ti][0], 0, 0, 0);
                 }
             }
         }
