@@ -63,7 +63,22 @@ __global__ __launch_bounds__(256) void k_gn_partial(const T* __restrict__ x1, in
             src = x2 + (int64_t)n * s * c2 + (ch - c1);
             stride = c2;
         }
-        for (int64_t p = p0 + pl; p < p1; p += ppi) {
+        // 4 independent 16-byte loads in flight per thread (a single dependent load per iteration leaves the
+        // kernel latency-bound at ~2.6 TB/s)
+        int64_t p = p0 + pl;
+        for (; p + 3 * (int64_t)ppi < p1; p += 4 * (int64_t)ppi) {
+            float v0[8], v1[8], v2[8], v3[8];
+            load_octet<T>(src + p * stride, v0);
+            load_octet<T>(src + (p + ppi) * stride, v1);
+            load_octet<T>(src + (p + 2 * (int64_t)ppi) * stride, v2);
+            load_octet<T>(src + (p + 3 * (int64_t)ppi) * stride, v3);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                sum[j] += (v0[j] + v1[j]) + (v2[j] + v3[j]);
+                sq[j] = fmaf(v0[j], v0[j], fmaf(v1[j], v1[j], fmaf(v2[j], v2[j], fmaf(v3[j], v3[j], sq[j]))));
+            }
+        }
+        for (; p < p1; p += ppi) {
             float v[8];
             load_octet<T>(src + p * stride, v);
 #pragma unroll
@@ -230,7 +245,25 @@ __global__ __launch_bounds__(256) void k_gn_bwd_reduce(const T* __restrict__ g, 
             mu[j] = stats[((int64_t)n * 32 + grp) * 2 + 0];
             rs[j] = stats[((int64_t)n * 32 + grp) * 2 + 1];
         }
-        for (int64_t p = p0 + pl; p < p1; p += ppi) {
+        int64_t p = p0 + pl;
+        for (; p + ppi < p1; p += 2 * (int64_t)ppi) {      // two positions (4 loads) in flight
+            float xv[8], gv[8], xw[8], gw[8];
+            load_octet<T>(src + p * stride, xv);
+            load_octet<T>(gp + p * C, gv);
+            load_octet<T>(src + (p + ppi) * stride, xw);
+            load_octet<T>(gp + (p + ppi) * C, gw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float gq = gv[j], gr = gw[j];
+                if (pre_silu) {
+                    gq *= dsilu_f(fmaf(av[j], xv[j], bv[j]));
+                    gr *= dsilu_f(fmaf(av[j], xw[j], bv[j]));
+                }
+                r1[j] += gq + gr;
+                r2[j] = fmaf(gq, (xv[j] - mu[j]) * rs[j], fmaf(gr, (xw[j] - mu[j]) * rs[j], r2[j]));
+            }
+        }
+        for (; p < p1; p += ppi) {
             float xv[8], gv[8];
             load_octet<T>(src + p * stride, xv);
             load_octet<T>(gp + p * C, gv);
@@ -378,39 +411,53 @@ __device__ __forceinline__ void store_octet<float>(float* p, const float (&v)[8]
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_gn_bwd_apply(const T* __restrict__ g, const T* __restrict__ x1, int c1,
-                                                      const T* __restrict__ x2, int c2, int64_t s,
+                                                      const T* __restrict__ x2, int c2, int64_t s, int nblk,
                                                       const float* __restrict__ a, const float* __restrict__ b, int pre_silu,
                                                       const float* __restrict__ cA, const float* __restrict__ cP,
                                                       const float* __restrict__ cQ, T* __restrict__ dx1, T* __restrict__ dx2,
                                                       int acc1, int acc2) {
+    // same thread -> (channel octet, position lane) map as the reducers: the 5 per-channel coefficients live in
+    // registers for the whole position walk (the elementwise form re-loaded them and divided indices per element)
     const int C = c1 + c2;
     const int OCT = C >> 3;
+    const int ppi = 256 / OCT;
+    const int tid = threadIdx.x;
+    const int oc = tid % OCT, pl = tid / OCT;
+    if (pl >= ppi) return;
+    const int n = blockIdx.y, blk = blockIdx.x;
+    const int64_t per = (s + nblk - 1) / nblk;
+    const int64_t p0 = (int64_t)blk * per;
+    const int64_t p1 = (p0 + per < s) ? p0 + per : s;
+    const int ch = oc * 8;
     const int cpg = C / 32;
-    const int n = blockIdx.y;
-    const int64_t total = s * OCT;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t p = i / OCT;
-        const int oc = (int)(i - p * OCT);
-        const int ch = oc * 8;
-        const bool first = ch < c1;
-        const T* xs = first ? x1 + ((int64_t)n * s + p) * c1 + ch : x2 + ((int64_t)n * s + p) * c2 + (ch - c1);
-        T* dst = first ? dx1 + ((int64_t)n * s + p) * c1 + ch : dx2 + ((int64_t)n * s + p) * c2 + (ch - c1);
-        const int accf = first ? acc1 : acc2;
+    const bool first = ch < c1;
+    const T* xs = first ? x1 + (int64_t)n * s * c1 + ch : x2 + (int64_t)n * s * c2 + (ch - c1);
+    T* dst = first ? dx1 + (int64_t)n * s * c1 + ch : dx2 + (int64_t)n * s * c2 + (ch - c1);
+    const int64_t stride = first ? c1 : c2;
+    const int accf = first ? acc1 : acc2;
+    const T* gp = g + (int64_t)n * s * C + ch;
+    float av[8], bv[8], ca[8], cp[8], cq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int64_t nc = (int64_t)n * C + ch + j;
+        const int grp = (ch + j) / cpg;
+        av[j] = a[nc]; bv[j] = b[nc]; ca[j] = cA[nc];
+        cp[j] = cP[(int64_t)n * 32 + grp]; cq[j] = cQ[(int64_t)n * 32 + grp];
+    }
+    for (int64_t p = p0 + pl; p < p1; p += ppi) {
         float xv[8], gv[8], ov[8];
-        load_octet<T>(xs, xv);
-        load_octet<T>(g + ((int64_t)n * s + p) * C + ch, gv);
-        if (accf) load_octet<T>(dst, ov);
+        load_octet<T>(xs + p * stride, xv);
+        load_octet<T>(gp + p * C, gv);
+        if (accf) load_octet<T>(dst + p * stride, ov);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int64_t nc = (int64_t)n * C + ch + j;
             float gq = gv[j];
-            if (pre_silu) gq *= dsilu_f(fmaf(a[nc], xv[j], b[nc]));
-            const int grp = (ch + j) / cpg;
-            float r = fmaf(cA[nc], gq, fmaf(cQ[(int64_t)n * 32 + grp], xv[j], cP[(int64_t)n * 32 + grp]));
+            if (pre_silu) gq *= dsilu_f(fmaf(av[j], xv[j], bv[j]));
+            float r = fmaf(ca[j], gq, fmaf(cq[j], xv[j], cp[j]));
             if (accf) r += ov[j];
             ov[j] = r;
         }
-        store_octet<T>(dst, ov);
+        store_octet<T>(dst + p * stride, ov);
     }
 }
 
@@ -422,16 +469,18 @@ extern "C" int rho_gn_bwd_apply(const void* g, const void* x1, int64_t c1, const
     if (c2 > 0 && !dx2) return RHO_E_ARG;
     const int64_t C = c1 + c2;
     if (C % 32 != 0 || c1 % 8 != 0 || c2 % 8 != 0) return RHO_E_ALIGN;
-    int64_t gx = (s * (C / 8) + 255) / 256;
-    if (gx > 1024) gx = 1024;
-    dim3 grid((unsigned)gx, (unsigned)n), block(256);
+    if (C > 2048) return RHO_E_SHAPE;
+    int nblk = (int)((s + 511) / 512);          // finer than the reducers: nothing to combine afterwards
+    if (nblk < 1) nblk = 1;
+    if (nblk > 256) nblk = 256;
+    dim3 grid((unsigned)nblk, (unsigned)n), block(256);
     if (dtype == RHO_BF16)
         hipLaunchKernelGGL(k_gn_bwd_apply<bf16_raw>, grid, block, 0, as_stream(stream), (const bf16_raw*)g, (const bf16_raw*)x1,
-                           (int)c1, (const bf16_raw*)x2, (int)c2, s, a, b, pre_silu, cA, cP, cQ, (bf16_raw*)dx1, (bf16_raw*)dx2, acc1,
-                           acc2);
+                           (int)c1, (const bf16_raw*)x2, (int)c2, s, nblk, a, b, pre_silu, cA, cP, cQ, (bf16_raw*)dx1, (bf16_raw*)dx2,
+                           acc1, acc2);
     else if (dtype == RHO_F32)
         hipLaunchKernelGGL(k_gn_bwd_apply<float>, grid, block, 0, as_stream(stream), (const float*)g, (const float*)x1, (int)c1,
-                           (const float*)x2, (int)c2, s, a, b, pre_silu, cA, cP, cQ, (float*)dx1, (float*)dx2, acc1, acc2);
+                           (const float*)x2, (int)c2, s, nblk, a, b, pre_silu, cA, cP, cQ, (float*)dx1, (float*)dx2, acc1, acc2);
     else
         return RHO_E_ARG;
     RHO_LAUNCH_CHECK();
