@@ -42,9 +42,30 @@ struct ConvK {
     int res_add_stride;
     int y2_cl;            // y2 is channels-last [.., cout - split] (dgrad of a concatenated input) instead of channel-major
     const char* res2;     // residual for the y2 region (channels-last only): in-place gradient accumulation
+    int pair_lg;          // -1: none; else log2 of the row-index bit that pairs two 8-wide halo rows 8 (mod 16) positions apart
     int zs_h, zs_w;       // zero-stuffed input (dgrad of a stride-2 conv): virtual extent H/W, source extent Hs/Ws
     int Hs, Ws;
 };
+
+
+// Column c (0..31) of MFMA tile m (0..7 = wave*2 + j) -> index of the output position inside the 256-position tile.
+// ds_read_b128 serves a wave in 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): with an odd slot pitch a
+// group is conflict-free iff its 16 halo positions are distinct mod 16.  So the columns are ordered group-major and
+// each group gets either 16 consecutive positions of one row (TW >= 16) or, for 8-wide tiles, two rows whose halo
+// offset is 8 (mod 16) -- the row bit `pair_lg` chosen on the host.  (PMC before this map: SQ_LDS_BANK_CONFLICT was
+// 40-50 % of SQ_LDS_IDX_ACTIVE in this kernel.)
+__device__ __forceinline__ int tile_position(int m, int c, int TW, int pair_lg) {
+    const int q = c >> 2;
+    const int g = (0x96 >> q) & 1;                 // lane group of this column
+    const int k = ((q >> 1) << 2) | (c & 3);       // rank inside the group, 0..15
+    const int u = 2 * m + g;                       // 16-position unit, 0..15
+    if (TW == 8 && pair_lg >= 0) {
+        const int lo = u & ((1 << pair_lg) - 1);
+        const int row = ((u >> pair_lg) << (pair_lg + 1)) | lo | ((k >> 3) << pair_lg);
+        return row * 8 + (k & 7);
+    }
+    return u * 16 + k;
+}
 
 template <typename T, int KD, int KH, int KW, int BM, int MAXP>
 __global__ __launch_bounds__(256) void k_conv(const ConvK p) {
@@ -113,7 +134,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvK p) {
     int offd[2], offh[2][KH], offw[2][KW];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int pp = wave * 64 + j * 32 + (lane & 31);
+        const int pp = tile_position(wave * 2 + j, lane & 31, p.TW, p.pair_lg);
         const int pw = pp % p.TW;
         const int ph = (pp / p.TW) % p.TH;
         const int pd = pp / (p.TW * p.TH);
@@ -148,28 +169,38 @@ __global__ __launch_bounds__(256) void k_conv(const ConvK p) {
     const char* const w_src0 = p.w + ((size_t)co0 + (tid >> 2)) * wrow_bytes + piece * 16;
     const size_t w_tap_stride = (size_t)p.coutp * wrow_bytes;
     const int w_dst0 = (tid >> 2) * PITCH + piece * 16;
-    // weights are fetched PD taps ahead of their use (L2 latency ~1.5k cycles vs ~0.5k cycles of MFMA per tap):
-    // a register ring of PD sets, set (step % PD) holds step's tile; the LDS ring stays 2 deep.
-    constexpr int PD = (NT % 3 == 0) ? 3 : 1;
-    uint4 wq0[PD], wq1[PD];
+    // Weights: G taps form one barrier step (G = 3 for the narrow-cout variants, where 8 MFMAs per barrier would be
+    // barrier-bound), fetched PD steps ahead of their use (L2 latency ~1.5k cycles vs 0.25-0.5k cycles of MFMA per
+    // tap) into a register ring of PD sets; set (step % PD) holds that step's G tiles; the LDS ring stays 2 deep.
+    constexpr int G = 1;   // measured: G = 3 on the narrow-cout variants changes nothing (barriers are not their limiter)
+    constexpr int NS = NT / G;
+    constexpr int PD = (NS % 3 == 0) ? 3 : 1;
+    constexpr int SLOT = G * BM * PITCH;
+    uint4 wq0[PD][G], wq1[PD][G];
 #pragma unroll
-    for (int i = 0; i < PD; ++i) wq0[i] = wq1[i] = make_uint4(0u, 0u, 0u, 0u);
-#define RHO_LOAD_W(set_, ck_, tap_)                                                                   \
-    do {                                                                                             \
-        const char* ws_ = w_src0 + (size_t)(tap_) * w_tap_stride + (size_t)(ck_) * 64;               \
-        if (w_active) wq0[set_] = *reinterpret_cast<const uint4*>(ws_);                              \
-        if constexpr (WROWS == 2) wq1[set_] = *reinterpret_cast<const uint4*>(ws_ + 64 * wrow_bytes); \
+    for (int i = 0; i < PD; ++i)
+#pragma unroll
+        for (int g = 0; g < G; ++g) wq0[i][g] = wq1[i][g] = make_uint4(0u, 0u, 0u, 0u);
+#define RHO_LOAD_W(set_, ck_, st_)                                                                       \
+    do {                                                                                                \
+        _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_) {                                              \
+            const char* ws_ = w_src0 + (size_t)((st_) * G + g_) * w_tap_stride + (size_t)(ck_) * 64;    \
+            if (w_active) wq0[set_][g_] = *reinterpret_cast<const uint4*>(ws_);                         \
+            if constexpr (WROWS == 2) wq1[set_][g_] = *reinterpret_cast<const uint4*>(ws_ + 64 * wrow_bytes); \
+        }                                                                                               \
     } while (0)
-#define RHO_STORE_W(buf_, set_)                                                                      \
-    do {                                                                                             \
-        char* wd_ = wbuf + (size_t)(buf_) * BM * PITCH + w_dst0;                                     \
-        if (w_active) *reinterpret_cast<uint4*>(wd_) = wq0[set_];                                    \
-        if constexpr (WROWS == 2) *reinterpret_cast<uint4*>(wd_ + 64 * PITCH) = wq1[set_];           \
+#define RHO_STORE_W(buf_, set_)                                                                         \
+    do {                                                                                                \
+        _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_) {                                              \
+            char* wd_ = wbuf + (size_t)(buf_) * SLOT + g_ * BM * PITCH + w_dst0;                        \
+            if (w_active) *reinterpret_cast<uint4*>(wd_) = wq0[set_][g_];                               \
+            if constexpr (WROWS == 2) *reinterpret_cast<uint4*>(wd_ + 64 * PITCH) = wq1[set_][g_];      \
+        }                                                                                               \
     } while (0)
 
-    // prologue: steps 0 .. PD-1 in flight, step 0 landed in LDS slot 0
+    // prologue: steps 0 .. PD-1 of chunk 0 in flight (PD <= NS), step 0 landed in LDS slot 0
 #pragma unroll
-    for (int i = 0; i < PD; ++i) RHO_LOAD_W(i, 0, i % NT);     // PD <= NT always
+    for (int i = 0; i < PD; ++i) RHO_LOAD_W(i, 0, i);
     RHO_STORE_W(0, 0);
     int cur = 0;
 
@@ -254,54 +285,52 @@ __global__ __launch_bounds__(256) void k_conv(const ConvK p) {
         }
         __syncthreads();
 
-        // ---- all taps out of the resident tile
+        // ---- all taps out of the resident tile, G taps per barrier step
 #pragma unroll
-        for (int kd = 0; kd < KD; ++kd) {
-#pragma unroll
-            for (int kh = 0; kh < KH; ++kh) {
-#pragma unroll
-                for (int kw = 0; kw < KW; ++kw) {
-                    const int tap = (kd * KH + kh) * KW + kw;
-                    const bool has_next = !(ck == nck - 1 && tap == NT - 1);
-                    // step q = ck*NT + tap: its register set (tap % PD) went to LDS one step ago -> refill it with
-                    // step q + PD now, so the fetch has PD taps of MFMA work to hide under; at the end of this step
-                    // step q + 1 (fetched PD - 1 steps ago) is handed to the other LDS slot.
-                    // (unconditional: past the end it re-reads the last chunk's tile, so that the number of loads in
-                    //  flight is static and the compiler can wait with a counted vmcnt instead of draining to 0)
-                    {
-                        const int ntap = (tap + PD < NT) ? tap + PD : tap + PD - NT;
-                        const int nckk = (tap + PD < NT) ? ck : min(ck + 1, nck - 1);
-                        RHO_LOAD_W(tap % PD, nckk, ntap);
-                    }
-                    // next chunk's halo: issued AFTER this tap's weight fetch (vmcnt retires in order, so the counted
-                    // waits for the next PD-1 taps' weights do not drain these loads) and unconditionally (static count)
-                    if constexpr (HPF) {
-                        if (tap == TPF) {
-                            __builtin_amdgcn_sched_barrier(0);     // keep the halo loads younger than the weight fetch above
-                            RHO_HALO_LOAD(min(ck + 1, nck - 1));
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                    const char* wcur = wbuf + (size_t)cur * BM * PITCH + a_off;
-                    const int dtap = kd * p.IH * p.IW * PITCH;
-                    const char* b0p = halo + (dtap + offd[0] + offh[0][kh] + offw[0][kw]);
-                    const char* b1p = halo + (dtap + offd[1] + offh[1][kh] + offw[1][kw]);
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const uint4 b0 = *reinterpret_cast<const uint4*>(b0p + 32 * s);
-                        const uint4 b1 = *reinterpret_cast<const uint4*>(b1p + 32 * s);
-#pragma unroll
-                        for (int mi = 0; mi < MT; ++mi) {
-                            const uint4 a = *reinterpret_cast<const uint4*>(wcur + mi * 32 * PITCH + 32 * s);
-                            mma_step<T>(a, b0, acc[mi][0]);
-                            mma_step<T>(a, b1, acc[mi][1]);
-                        }
-                    }
-                    if (has_next) RHO_STORE_W(cur ^ 1, (tap + 1) % PD);
-                    __syncthreads();
-                    cur ^= 1;
+        for (int st = 0; st < NS; ++st) {
+            const bool has_next = !(ck == nck - 1 && st == NS - 1);
+            // step q = ck*NS + st: its register set (st % PD) went to LDS one step ago -> refill it with step q + PD
+            // now, so the fetch has PD steps of MFMA work to hide under; at the end of this step, step q + 1 (fetched
+            // PD - 1 steps ago) is handed to the other LDS slot.  Unconditional (past the end it re-reads the last
+            // chunk's tiles) so that the number of loads in flight is static and the compiler waits with a counted
+            // vmcnt instead of draining to 0.
+            {
+                const int nst = (st + PD < NS) ? st + PD : st + PD - NS;
+                const int nckk = (st + PD < NS) ? ck : min(ck + 1, nck - 1);
+                RHO_LOAD_W(st % PD, nckk, nst);
+            }
+            // next chunk's halo: issued AFTER this step's weight fetch (vmcnt retires in order, so the counted waits
+            // for the next PD-1 steps' weights do not drain these loads) and unconditionally (static count)
+            if constexpr (HPF) {
+                if (st * G == TPF) {
+                    __builtin_amdgcn_sched_barrier(0);     // keep the halo loads younger than the weight fetch above
+                    RHO_HALO_LOAD(min(ck + 1, nck - 1));
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int tap = st * G + g;
+                const int kd = tap / (KH * KW), kh = (tap / KW) % KH, kw = tap % KW;
+                const char* wcur = wbuf + (size_t)cur * SLOT + g * BM * PITCH + a_off;
+                const int dtap = kd * p.IH * p.IW * PITCH;
+                const char* b0p = halo + (dtap + offd[0] + offh[0][kh] + offw[0][kw]);
+                const char* b1p = halo + (dtap + offd[1] + offh[1][kh] + offw[1][kw]);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const uint4 b0 = *reinterpret_cast<const uint4*>(b0p + 32 * s);
+                    const uint4 b1 = *reinterpret_cast<const uint4*>(b1p + 32 * s);
+#pragma unroll
+                    for (int mi = 0; mi < MT; ++mi) {
+                        const uint4 a = *reinterpret_cast<const uint4*>(wcur + mi * 32 * PITCH + 32 * s);
+                        mma_step<T>(a, b0, acc[mi][0]);
+                        mma_step<T>(a, b1, acc[mi][1]);
+                    }
+                }
+            }
+            if (has_next) RHO_STORE_W(cur ^ 1, (st + 1) % PD);
+            __syncthreads();
+            cur ^= 1;
         }
     }
 
@@ -313,7 +342,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvK p) {
     const bool cl_region = (co0 < p.split);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int pp = wave * 64 + j * 32 + (lane & 31);
+        const int pp = tile_position(wave * 2 + j, lane & 31, p.TW, p.pair_lg);
         const int pw = pp % p.TW;
         const int ph = (pp / p.TW) % p.TH;
         const int pd = pp / (p.TW * p.TH);
@@ -491,7 +520,10 @@ extern "C" int rho_conv_nd_fwd(const rho_conv_desc* dp, void* stream) {
     else if (d.coutp % 64 == 0 && (d.split % 64 == 0)) BM = 64;
 
     const size_t lds_cap = 160 * 1024;
-    int np_cap = (int)((lds_cap - 2 * (size_t)BM * PITCH) / PITCH);
+    const int taps = d.kd * d.kh * d.kw;
+    const int G = 1;                                            // taps per weight-ring slot (matches the kernel)
+    (void)taps;
+    int np_cap = (int)((lds_cap - 2 * (size_t)G * BM * PITCH) / PITCH);
     if (np_cap > 28 * 64) np_cap = 28 * 64;
     // prefer the small-halo (2 blocks / CU) configuration when it exists
     TileChoice t = choose_tile(d, k.D, k.Do, k.Ho, k.Wo, 640);
@@ -507,12 +539,22 @@ extern "C" int rho_conv_nd_fwd(const rho_conv_desc* dp, void* stream) {
     k.sh = d.sh; k.sw = d.sw; k.up_h = d.up_h; k.up_w = d.up_w; k.pre_silu = d.pre_silu; k.y2_f32 = d.y2_f32;
     k.TD = t.TD; k.TH = t.TH; k.TW = t.TW; k.ID = t.ID; k.IH = t.IH; k.IW = t.IW; k.NP = t.NP;
     k.tiles_h = cdiv(k.Ho, t.TH); k.tiles_w = cdiv(k.Wo, t.TW);
+    // 8-wide tiles: pair rows (pd*TH + ph) differing in one bit whose halo offset is 8 (mod 16) positions
+    k.pair_lg = -1;
+    if (t.TW == 8 && d.sw == 1 && d.sh == 1 && !d.up_h && !d.up_w) {
+        int lgTH = 0;
+        while ((1 << lgTH) < t.TH) ++lgTH;
+        for (int b = 0; b < 5 && k.pair_lg < 0; ++b) {
+            const long long delta = (b < lgTH) ? (long long)(1 << b) * t.IW : (long long)(1 << (b - lgTH)) * t.IH * t.IW;
+            if ((1 << b) < t.TD * t.TH && delta % 16 == 8) k.pair_lg = b;
+        }
+    }
     if (d.pre_a && !d.pre_b) return RHO_E_ARG;
 
     const long long tiles = (long long)cdiv(k.Do, t.TD) * k.tiles_h * k.tiles_w;
     if (tiles > 0x7FFFFFFFLL || d.coutp / BM > 65535 || gridz > 65535) return RHO_E_SHAPE;
     dim3 grid((unsigned)tiles, (unsigned)(d.coutp / BM), (unsigned)gridz);
-    const size_t lds = (size_t)t.NP * PITCH + 2 * (size_t)BM * PITCH;
+    const size_t lds = (size_t)t.NP * PITCH + 2 * (size_t)G * BM * PITCH;
     const int maxp = cdiv(t.NP, 64);
     hipStream_t st = as_stream(stream);
     if (d.dtype == RHO_BF16) return launch_taps<bf16_raw>(d, k, BM, maxp, grid, lds, st);
