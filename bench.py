@@ -121,9 +121,19 @@ def roofline_of(plan, args):
                         f"cin={p_.get('cin', '')} cout={p_.get('cout', '')} taps={p_.get('taps', '')} pos={p_.get('positions', '')}\n")
     peak = MFMA_PEAK_TFLOPS[args.dtype]
     achieved = fl / (ms * 1e-3) / 1e12
+    # HBM traffic of the same launches from PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
+    # --pmc passes; collected offline with rocprofv3 on this command, see profiles/): bench.py cannot run the profiler
+    traffic = traffic_note = None
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic_conv3.json")
+    if os.path.exists(tpath) and args.dtype == "bf16" and args.batch == 32 and args.grid == 64 and args.dims == 3 and args.mc == 64:
+        with open(tpath) as f:
+            tj = json.load(f)
+        traffic, traffic_note = tj["hbm_bytes_per_step"], "profiles/r01_pmc_traffic_conv3.json (bytes per step over the same launches)"
+    alg_bytes = sum(p["bytes"] for p in conv3)
     return {
         "bound": "mfma", "kernel": "k_conv (3x3x3 implicit GEMM, LDS halo tile)", "achieved": achieved, "peak": peak,
-        "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+        "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_note,
+        "algorithmic_bytes_per_step": alg_bytes,
         "launches_per_step": len(conv3), "avg_launch_ms": ms / max(1, len(conv3)),
         "algorithmic_flops_per_step": fl, "kernel_ms_per_step": ms, "all_kernels_ms_per_step": sum(p["ms"] for p in prof),
         "by_kind_ms": {k: round(v["ms"], 3) for k, v in kinds.items()},
@@ -138,10 +148,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
+    local = local % max(1, torch.cuda.device_count())      # (only differs from LOCAL_RANK when ranks share a GPU in rehearsals)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # "nccl" IS RCCL on ROCm; RHO_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals
+        dist.init_process_group(os.environ.get("RHO_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 
