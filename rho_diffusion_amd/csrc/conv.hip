@@ -67,14 +67,21 @@ __device__ __forceinline__ int tile_position(int m, int c, int TW, int pair_lg) 
     return u * 16 + k;
 }
 
-template <typename T, int KD, int KH, int KW, int BM, int MAXP>
-__global__ __launch_bounds__(256) void k_conv(const ConvK p) {
+// NW = 4: each wave owns 64 positions x all BM couts.  NW = 8 (BM = 128): waves form a 2 (cout halves) x 4 (position
+// quarters) grid, 64 couts x 64 positions each, so the workgroup keeps two waves on every SIMD (64 accumulator registers
+// per wave instead of 128) and one wave's LDS / barrier / vmcnt waits are covered by the other's MFMAs.
+// MAXP = halo slots per thread (halo positions <= MAXP * NW * 16).
+template <typename T, int KD, int KH, int KW, int BM, int MAXP, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CK = ET<T>::CK;
     constexpr int PE = ET<T>::PE;
     constexpr int NT = KD * KH * KW;
-    constexpr int MT = BM / 32;        // 32-row cout tiles per wave
-    constexpr int WROWS = (BM + 63) / 64;  // weight-tile rows per thread (64 rows x 4 pieces per pass)
+    constexpr int NTHR = NW * 64;
+    constexpr int RPP = NTHR / 4;          // rows (halo positions / weight rows) covered per staging pass
+    constexpr int WCO = NW / 4;            // waves along cout
+    constexpr int MT = BM / 32 / WCO;      // 32-row cout tiles per wave
+    constexpr int WROWS = (BM + RPP - 1) / RPP;  // weight-tile rows per thread
 
     char* const halo = smem;
     char* const wbuf = smem + (size_t)p.NP * PITCH;
@@ -82,6 +89,8 @@ __global__ __launch_bounds__(256) void k_conv(const ConvK p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    const int wpos = wave & 3;             // position quarter of this wave
+    const int wco = wave >> 2;             // cout half (NW == 8)
     const int half = lane >> 5;
     const int piece = tid & 3;
 
@@ -106,7 +115,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvK p) {
         const int ihw = p.IH * p.IW;
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
-            const int hp = (tid >> 2) + 64 * i;
+            const int hp = (tid >> 2) + RPP * i;
             int pos = -2, smp = 0;
             if (hp < p.NP) {
                 const int id = hp / ihw;
@@ -134,7 +143,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvK p) {
     int offd[2], offh[2][KH], offw[2][KW];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int pp = tile_position(wave * 2 + j, lane & 31, p.TW, p.pair_lg);
+        const int pp = tile_position(wpos * 2 + j, lane & 31, p.TW, p.pair_lg);
         const int pw = pp % p.TW;
         const int ph = (pp / p.TW) % p.TH;
         const int pd = pp / (p.TW * p.TH);
@@ -150,7 +159,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvK p) {
             offw[j][kw] = iw * PITCH;
         }
     }
-    const int a_off = (lane & 31) * PITCH + 16 * half;
+    const int a_off = (wco * (BM / WCO) + (lane & 31)) * PITCH + 16 * half;
 
     f32x16_t acc[MT][2];
 #pragma unroll
@@ -165,7 +174,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvK p) {
 
     // weight tile: BM rows x 4 pieces of 16 B; thread -> row (tid>>2) + 64*k, piece tid&3.
     // (plain scalars, no arrays by reference: those end up in scratch)
-    const bool w_active = (BM >= 64) || (tid < BM * 4);
+    const bool w_active = (BM >= RPP) || (tid < BM * 4);
     const char* const w_src0 = p.w + ((size_t)co0 + (tid >> 2)) * wrow_bytes + piece * 16;
     const size_t w_tap_stride = (size_t)p.coutp * wrow_bytes;
     const int w_dst0 = (tid >> 2) * PITCH + piece * 16;
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvK p) {
         _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_) {                                              \
             const char* ws_ = w_src0 + (size_t)((st_) * G + g_) * w_tap_stride + (size_t)(ck_) * 64;    \
             if (w_active) wq0[set_][g_] = *reinterpret_cast<const uint4*>(ws_);                         \
-            if constexpr (WROWS == 2) wq1[set_][g_] = *reinterpret_cast<const uint4*>(ws_ + 64 * wrow_bytes); \
+            if constexpr (WROWS == 2) wq1[set_][g_] = *reinterpret_cast<const uint4*>(ws_ + RPP * wrow_bytes); \
         }                                                                                               \
     } while (0)
 #define RHO_STORE_W(buf_, set_)                                                                         \
@@ -194,7 +203,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvK p) {
         _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_) {                                              \
             char* wd_ = wbuf + (size_t)(buf_) * SLOT + g_ * BM * PITCH + w_dst0;                        \
             if (w_active) *reinterpret_cast<uint4*>(wd_) = wq0[set_][g_];                               \
-            if constexpr (WROWS == 2) *reinterpret_cast<uint4*>(wd_ + 64 * PITCH) = wq1[set_][g_];      \
+            if constexpr (WROWS == 2) *reinterpret_cast<uint4*>(wd_ + RPP * PITCH) = wq1[set_][g_];     \
         }                                                                                               \
     } while (0)
 
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvK p) {
     // issued into registers while the last taps of the current chunk run on the matrix cores, and only the
     // prologue + LDS write happens between chunks (issue-early / write-late).  Otherwise (>= 2 workgroups per CU
     // overlap each other) load and write in small batches to keep the register footprint down.
-    constexpr bool HPF = (BM >= 128) && (MAXP <= 10);
+    constexpr bool HPF = (BM >= 128) && (MAXP * RPP <= 640);
     constexpr int TPF = (NT > 6) ? NT - 6 : 0;        // tap at which the next chunk's loads are issued
     uint4 hv[HPF ? MAXP : 1];
     auto halo_src = [&](int ck_, const char*& src, int& cs, int& csrc) {
@@ -243,7 +252,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvK p) {
                             const size_t co = (size_t)smp * p.cin + c + piece * PE;
                             u = apply_pre<T>(u, p.pre_a + co, p.pre_b + co, p.pre_silu);
                         }
-                        const int hp = (tid >> 2) + 64 * i;
+                        const int hp = (tid >> 2) + RPP * i;
                         *reinterpret_cast<uint4*>(halo + hp * PITCH + piece * 16) = u;
                     }
                 }
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvK p) {
                                     const size_t co = (size_t)smp * p.cin + c + piece * PE;
                                     u = apply_pre<T>(u, p.pre_a + co, p.pre_b + co, p.pre_silu);
                                 }
-                                const int hp = (tid >> 2) + 64 * i;
+                                const int hp = (tid >> 2) + RPP * i;
                                 *reinterpret_cast<uint4*>(halo + hp * PITCH + piece * 16) = u;
                             }
                         }
@@ -342,7 +351,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvK p) {
     const bool cl_region = (co0 < p.split);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int pp = tile_position(wave * 2 + j, lane & 31, p.TW, p.pair_lg);
+        const int pp = tile_position(wpos * 2 + j, lane & 31, p.TW, p.pair_lg);
         const int pw = pp % p.TW;
         const int ph = (pp / p.TW) % p.TH;
         const int pd = pp / (p.TW * p.TH);
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(256) void k_conv(const ConvK p) {
         for (int mi = 0; mi < MT; ++mi) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const int co = co0 + mi * 32 + rg * 8 + half * 4;
+                const int co = co0 + wco * (BM / WCO) + mi * 32 + rg * 8 + half * 4;
                 const float4 bv = *reinterpret_cast<const float4*>(p.bias + co);
                 float v0 = acc[mi][j][rg * 4 + 0] + bv.x;
                 float v1 = acc[mi][j][rg * 4 + 1] + bv.y;
@@ -423,38 +432,42 @@ namespace {
 
 using namespace rho_conv;
 
-template <typename T, int KD, int KH, int KW, int BM, int MAXP>
+template <typename T, int KD, int KH, int KW, int BM, int MAXP, int NW>
 int launch_one(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
-    auto fn = k_conv<T, KD, KH, KW, BM, MAXP>;
+    auto fn = k_conv<T, KD, KH, KW, BM, MAXP, NW>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, k);
+    hipLaunchKernelGGL(fn, grid, dim3(NW * 64), lds, st, k);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
 
+// np = halo positions of the chosen tile.  BM = 128 runs 8 waves (slots per thread: 5 for np <= 640, else 14).
 template <typename T, int KD, int KH, int KW>
-int launch_bm(const ConvK& k, int BM, int maxp, dim3 grid, size_t lds, hipStream_t st) {
-#define RHO_CASE(bm)                                                                \
-    if (BM == bm) {                                                                 \
-        if (maxp <= 10) return launch_one<T, KD, KH, KW, bm, 10>(k, grid, lds, st); \
-        return launch_one<T, KD, KH, KW, bm, 28>(k, grid, lds, st);                 \
+int launch_bm(const ConvK& k, int BM, int np, dim3 grid, size_t lds, hipStream_t st) {
+    if (BM == 128) {
+        if (np <= 640) return launch_one<T, KD, KH, KW, 128, 5, 8>(k, grid, lds, st);
+        return launch_one<T, KD, KH, KW, 128, 14, 8>(k, grid, lds, st);
+    }
+#define RHO_CASE(bm)                                                                   \
+    if (BM == bm) {                                                                    \
+        if (np <= 640) return launch_one<T, KD, KH, KW, bm, 10, 4>(k, grid, lds, st);  \
+        return launch_one<T, KD, KH, KW, bm, 28, 4>(k, grid, lds, st);                 \
     }
     RHO_CASE(32)
     RHO_CASE(64)
-    RHO_CASE(128)
 #undef RHO_CASE
     return RHO_E_ARG;
 }
 
 template <typename T>
-int launch_taps(const rho_conv_desc& d, const ConvK& k, int BM, int maxp, dim3 grid, size_t lds, hipStream_t st) {
-    if (d.kd == 3 && d.kh == 3 && d.kw == 3) return launch_bm<T, 3, 3, 3>(k, BM, maxp, grid, lds, st);
-    if (d.kd == 1 && d.kh == 3 && d.kw == 3) return launch_bm<T, 1, 3, 3>(k, BM, maxp, grid, lds, st);
-    if (d.kd == 1 && d.kh == 1 && d.kw == 3) return launch_bm<T, 1, 1, 3>(k, BM, maxp, grid, lds, st);
-    if (d.kd == 1 && d.kh == 1 && d.kw == 1) return launch_bm<T, 1, 1, 1>(k, BM, maxp, grid, lds, st);
+int launch_taps(const rho_conv_desc& d, const ConvK& k, int BM, int np, dim3 grid, size_t lds, hipStream_t st) {
+    if (d.kd == 3 && d.kh == 3 && d.kw == 3) return launch_bm<T, 3, 3, 3>(k, BM, np, grid, lds, st);
+    if (d.kd == 1 && d.kh == 3 && d.kw == 3) return launch_bm<T, 1, 3, 3>(k, BM, np, grid, lds, st);
+    if (d.kd == 1 && d.kh == 1 && d.kw == 3) return launch_bm<T, 1, 1, 3>(k, BM, np, grid, lds, st);
+    if (d.kd == 1 && d.kh == 1 && d.kw == 1) return launch_bm<T, 1, 1, 1>(k, BM, np, grid, lds, st);
     return RHO_E_ARG;
 }
 
@@ -555,8 +568,7 @@ extern "C" int rho_conv_nd_fwd(const rho_conv_desc* dp, void* stream) {
     if (tiles > 0x7FFFFFFFLL || d.coutp / BM > 65535 || gridz > 65535) return RHO_E_SHAPE;
     dim3 grid((unsigned)tiles, (unsigned)(d.coutp / BM), (unsigned)gridz);
     const size_t lds = (size_t)t.NP * PITCH + 2 * (size_t)G * BM * PITCH;
-    const int maxp = cdiv(t.NP, 64);
     hipStream_t st = as_stream(stream);
-    if (d.dtype == RHO_BF16) return launch_taps<bf16_raw>(d, k, BM, maxp, grid, lds, st);
-    return launch_taps<float>(d, k, BM, maxp, grid, lds, st);
+    if (d.dtype == RHO_BF16) return launch_taps<bf16_raw>(d, k, BM, t.NP, grid, lds, st);
+    return launch_taps<float>(d, k, BM, t.NP, grid, lds, st);
 }
