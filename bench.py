@@ -104,6 +104,15 @@ def by_kind(prof):
     return acc
 
 
+def dump_ops(path, prof):
+    with open(path, "w") as f:
+        for i, p_ in enumerate(prof):
+            tf = p_["flops"] / (p_["ms"] * 1e-3) / 1e12 if p_["ms"] > 0 else 0.0
+            gb = p_["bytes"] / (p_["ms"] * 1e-3) / 1e9 if p_["ms"] > 0 else 0.0
+            f.write(f"{i:4d} {p_['kind']:12s} ms={p_['ms']:8.3f} TF/s={tf:8.1f} GB/s={gb:8.1f} "
+                    f"cin={p_.get('cin', '')} cout={p_.get('cout', '')} taps={p_.get('taps', '')} pos={p_.get('positions', '')}\n")
+
+
 def roofline_of(plan, args):
     """Dominant kernel = the 3x3x3 conv: achieved = algorithmic FLOPs of its launches in one step / their summed
     durations, each launch bracketed by HIP events on the launch stream (plan.profile)."""
@@ -113,12 +122,7 @@ def roofline_of(plan, args):
     ms = sum(p["ms"] for p in conv3)
     kinds = by_kind(prof)
     if args.dump_ops:
-        with open(args.dump_ops, "w") as f:
-            for i, p_ in enumerate(prof):
-                tf = p_["flops"] / (p_["ms"] * 1e-3) / 1e12 if p_["ms"] > 0 else 0.0
-                gb = p_["bytes"] / (p_["ms"] * 1e-3) / 1e9 if p_["ms"] > 0 else 0.0
-                f.write(f"{i:4d} {p_['kind']:12s} ms={p_['ms']:8.3f} TF/s={tf:8.1f} GB/s={gb:8.1f} "
-                        f"cin={p_.get('cin', '')} cout={p_.get('cout', '')} taps={p_.get('taps', '')} pos={p_.get('positions', '')}\n")
+        dump_ops(args.dump_ops, prof)
     peak = MFMA_PEAK_TFLOPS[args.dtype]
     achieved = fl / (ms * 1e-3) / 1e12
     # HBM traffic of the same launches from PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
@@ -233,7 +237,10 @@ def main():
         results["train"] = dict(dt=dt, steps=tsteps, loss=float(last["loss"]))
         if rank == 0 and not args.no_roofline:
             tp = engine._last_train_plan
-            fk, bk = by_kind(tp.profile(repeats=1)), by_kind(tp.profile(repeats=1, backward=True))
+            bprof = tp.profile(repeats=1, backward=True)
+            fk, bk = by_kind(tp.profile(repeats=1)), by_kind(bprof)
+            if args.dump_ops:
+                dump_ops(args.dump_ops + ".bwd", bprof)
             results["train"]["breakdown"] = {"fwd": {k: round(v["ms"], 2) for k, v in fk.items()},
                                              "bwd": {k: round(v["ms"], 2) for k, v in bk.items()},
                                              "bwd_TFLOPs": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in bk.items()

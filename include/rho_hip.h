@@ -210,6 +210,13 @@ int rho_gn_bwd_apply(const void* g, const void* x1, int64_t c1, const void* x2, 
                      int64_t s, const float* a, const float* b, int pre_silu, const float* cA, const float* cP,
                      const float* cQ, void* dx1, void* dx2, int acc1, int acc2, void* stream);
 
+/* Materialised prologue  y[n,pos,:] = act(a[n,:] * concat(x1,x2)[n,pos,:] + b[n,:])  (channels-last, dtype of x),
+ * bit-identical to what the convolution loaders compute on the fly from the same a / b (GroupNorm32 + FiLM + SiLU,
+ * layers.py:71-74, unet_v2.py:285-289).  Used in front of rho_conv_nd_wgrad so that the weight gradient reads
+ * ready activations.  C = c1 + c2 a multiple of 8, c1 and c2 multiples of 8. */
+int rho_gn_apply(const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t n, int64_t s,
+                 const float* a, const float* b, int pre_silu, void* y, void* stream);
+
 /* Channel sums of a channels-last tensor (conv bias gradients; additive-embedding gradients):
  * out_nc[n*nc_stride + c] (+)= sum_pos x[n,pos,c];  out_c[c] (+)= sum_n out_nc[n][c] (optional).
  * partials: scratch sized like rho_gn_partial's. */

@@ -488,6 +488,86 @@ extern "C" int rho_gn_bwd_apply(const void* g, const void* x1, int64_t c1, const
 }
 
 // ------------------------------------------------------------------------------------------------
+// Materialised normalised activation  y[n,pos,c] = act(a[n,c] * x[n,pos,c] + b[n,c])  over the (virtual) concat
+// of one or two sources.  The forward convolutions never need it (their loaders apply the folded affine on the
+// fly); the weight gradient does: there every (cout-tile, cin-chunk) workgroup would otherwise redo the
+// exp/rcp of SiLU for the same input chunk with a single wave per SIMD to hide it.
+template <typename T>
+__global__ __launch_bounds__(256) void k_gn_apply(const T* __restrict__ x1, int c1, const T* __restrict__ x2, int c2, int64_t s,
+                                                  int nblk, const float* __restrict__ a, const float* __restrict__ b,
+                                                  int pre_silu, T* __restrict__ y) {
+    const int C = c1 + c2;
+    const int OCT = C >> 3;
+    const int ppi = 256 / OCT;
+    const int tid = threadIdx.x;
+    const int oc = tid % OCT, pl = tid / OCT;
+    if (pl >= ppi) return;
+    const int n = blockIdx.y, blk = blockIdx.x;
+    const int64_t per = (s + nblk - 1) / nblk;
+    const int64_t p0 = (int64_t)blk * per;
+    const int64_t p1 = (p0 + per < s) ? p0 + per : s;
+    const int ch = oc * 8;
+    const bool first = ch < c1;
+    const T* xs = first ? x1 + (int64_t)n * s * c1 + ch : x2 + (int64_t)n * s * c2 + (ch - c1);
+    const int64_t stride = first ? c1 : c2;
+    T* yp = y + (int64_t)n * s * C + ch;
+    float av[8], bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        av[j] = a[(int64_t)n * C + ch + j];
+        bv[j] = b[(int64_t)n * C + ch + j];
+    }
+    int64_t p = p0 + pl;
+    for (; p + 3 * ppi < p1; p += 4 * ppi) {       // four independent 16/32-byte loads in flight per thread
+        float xv[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) load_octet<T>(xs + (p + u * ppi) * stride, xv[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = fmaf(av[j], xv[u][j], bv[j]);
+                xv[u][j] = pre_silu ? silu_f(f) : f;
+            }
+            store_octet<T>(yp + (p + u * ppi) * C, xv[u]);
+        }
+    }
+    for (; p < p1; p += ppi) {
+        float xv[8];
+        load_octet<T>(xs + p * stride, xv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = fmaf(av[j], xv[j], bv[j]);
+            xv[j] = pre_silu ? silu_f(f) : f;
+        }
+        store_octet<T>(yp + p * C, xv);
+    }
+}
+
+extern "C" int rho_gn_apply(const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t n, int64_t s,
+                            const float* a, const float* b, int pre_silu, void* y, void* stream) {
+    if (!x1 || !a || !b || !y || n <= 0 || s <= 0) return RHO_E_ARG;
+    if (!x2) c2 = 0;
+    const int64_t C = c1 + c2;
+    if (C <= 0 || C % 8 != 0 || c1 % 8 != 0 || c2 % 8 != 0) return RHO_E_ALIGN;
+    if (C > 2048 || n > 65535) return RHO_E_SHAPE;
+    int nblk = (int)((s + 1023) / 1024);
+    if (nblk < 1) nblk = 1;
+    if (nblk > 256) nblk = 256;
+    dim3 grid((unsigned)nblk, (unsigned)n), block(256);
+    if (dtype == RHO_BF16)
+        hipLaunchKernelGGL(k_gn_apply<bf16_raw>, grid, block, 0, as_stream(stream), (const bf16_raw*)x1, (int)c1, (const bf16_raw*)x2,
+                           (int)c2, s, nblk, a, b, pre_silu, (bf16_raw*)y);
+    else if (dtype == RHO_F32)
+        hipLaunchKernelGGL(k_gn_apply<float>, grid, block, 0, as_stream(stream), (const float*)x1, (int)c1, (const float*)x2, (int)c2, s,
+                           nblk, a, b, pre_silu, (float*)y);
+    else
+        return RHO_E_ARG;
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Channel sums of a channels-last tensor (bias gradients, additive-embedding gradients):
 // finalisation of rho_gn_partial's first 8 lanes.   out_nc[n][c] = sum_pos x ;  out_c[c] (+)= sum_n out_nc
 __global__ __launch_bounds__(256) void k_chan_sum_finalize(const float* __restrict__ partials, int c, int nblk,

@@ -12,9 +12,16 @@
 //     fragments (8 consecutive k per lane) are produced by gfx950's transposing LDS read
 //     ds_read_b64_tr_b16 straight from the row-major tiles - no transposed copies.
 // The exact-f32 variant (v_mfma_f32_32x32x2_f32) needs one k per lane, i.e. plain ds_read_b32.
+#include <type_traits>
+
 #include "conv_common.h"
 
-#define DY_PITCH 144   // 128 B of dY channels (64 bf16 / 32 f32) + 16 B pad
+// LDS rows are UNPADDED: a transposing read touches, per half-wave, 4 consecutive k-rows x 64 contiguous bytes;
+// with 64-byte halo rows those are 256 contiguous bytes = all 64 banks once.  The 128-byte dY rows get the same
+// property by swapping their two 64-byte halves on rows with bit 1 set.
+#define XP 64          // halo row: 32 bf16 / 16 f32 channels
+#define DYP 128        // dY row: 64 bf16 / 32 f32 channels
+__device__ __forceinline__ int dy_swz(int row) { return ((row >> 1) & 1) << 6; }
 
 struct WgradK {
     const char* x1;
@@ -63,9 +70,11 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     constexpr int COT = 128 / (int)sizeof(T);        // cout tile: 64 bf16 / 32 f32
     constexpr int MT = COT / 32;
     constexpr bool IS_BF16 = sizeof(T) == 2;
+    constexpr int NKS = TAPSPLIT ? 16 : 4;           // 16-position k-steps of this wave per tile
+    constexpr bool KEEP_REL = (MAXP <= 10);          // big-halo (strided) variant recomputes instead of holding registers
 
-    char* const halo = smem;
-    char* const dyt = smem + (size_t)p.NP * PITCH;
+    char* const halo = smem;                          // MAXP*64 rows (rows >= NP are written with zeros, never read)
+    char* const dyt = smem + (size_t)MAXP * 64 * XP;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const int piece = tid & 3;
@@ -74,23 +83,39 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     const char* src;
     int cs, csrc;
     if (c < p.c1) { src = p.x1; cs = p.c1; csrc = c; } else { src = p.x2; cs = p.c2; csrc = c - p.c1; }
+    src += (size_t)csrc * sizeof(T) + piece * 16;
 
-    // halo slot -> (id, ih, iw), fixed for every tile
-    int sdec[MAXP];
+    // halo slot -> (id, ih, iw) and its offset (in positions) from the tile's first halo position: fixed for every tile
+    int sdec[MAXP], srel[KEEP_REL ? MAXP : 1];
     {
         const int ihw = p.IH * p.IW;
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
             const int hp = (tid >> 2) + 64 * i;
-            int v = -1;
+            int v = -1, rel = 0;
             if (hp < p.NP) {
                 const int id = hp / ihw;
                 const int r = hp - id * ihw;
                 const int ih = r / p.IW;
-                v = (id << 20) | (ih << 10) | (r - ih * p.IW);
+                const int iw = r - ih * p.IW;
+                v = (id << 20) | (ih << 10) | iw;
+                rel = (id * p.H + ih) * p.W + iw;
             }
             sdec[i] = v;
+            if constexpr (KEEP_REL) srel[i] = rel;
         }
+    }
+    // dY rows of this thread: (pd, ph, pw) and the offset from the tile's first output position
+    const int dpiece = tid & 7;
+    const bool dch_ok = (co0 + dpiece * PE) < p.dyw;
+    const char* const dsrc = p.dy + (size_t)(dch_ok ? co0 + dpiece * PE : 0) * sizeof(T);
+    int ddec[8], drel[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        const int pw = row & (p.TW - 1), ph = (row >> p.lgTW) & (p.TH - 1), pd = row >> (p.lgTW + p.lgTH);
+        ddec[i] = (pd << 20) | (ph << 10) | pw;
+        drel[i] = (pd * p.Ho + ph) * p.Wo + pw;
     }
 
     // taps of this wave
@@ -103,7 +128,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
         // branch-free inner loop (an exec-masked branch per tap pair serialises LDS latency with the MFMAs)
         const int tc = tap < NT ? tap : NT - 1;
         const int kd = tc / (KH * KW), kh = (tc / KW) % KH, kw = tc % KW;
-        tapoff[ti] = ((kd * p.IH + kh) * p.IW + kw) * PITCH;
+        tapoff[ti] = ((kd * p.IH + kh) * p.IW + kw) * XP;
     }
 
     f32x16_t acc[TPW][MT];
@@ -114,9 +139,29 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ti][mi][r] = 0.0f;
 
-    // lane geometry of the transposing reads
+    // lane geometry of the transposing reads; the LDS row offsets of this lane's k-rows depend only on the k-step,
+    // so they are computed once (not per tile and k-step: the decode costs ~20 VALU incl. integer multiplies)
     const int grp = lane >> 4, li = lane & 15, q = li >> 2, pq = li & 3;
     const int colb = 16 * (grp & 1) + 4 * pq;          // channel of this lane's 8-byte address within a 32-wide tile
+    const int ks0 = TAPSPLIT ? 0 : wave * NKS;
+    auto xrow_of = [&](int j, int tt) {
+        const int pp = 16 * (ks0 + j) + 8 * (grp >> 1) + 4 * tt + q;
+        const int pw = pp & (p.TW - 1), ph = (pp >> p.lgTW) & (p.TH - 1), pd = pp >> (p.lgTW + p.lgTH);
+        return ((pd * p.IH + ph * p.sh) * p.IW + pw * p.sw) * XP + colb * 2;
+    };
+    int xrow[KEEP_REL ? NKS : 1][2];
+    int arow[MT];                                      // dY fragment base of this lane (k-step 0, t = 0)
+    if constexpr (IS_BF16) {
+        if constexpr (KEEP_REL) {
+#pragma unroll
+            for (int j = 0; j < NKS; ++j)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) xrow[j][tt] = xrow_of(j, tt);
+        }
+        const int pp0 = 16 * ks0 + 8 * (grp >> 1) + q;   // + 16*j + 4*tt: bit 1 of the row index is q's
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) arow[mi] = pp0 * DYP + ((mi * 64) ^ dy_swz(q)) + colb * 2;
+    }
 
     const int tile0 = blockIdx.x * p.tiles_per_block;
     const int tile1 = min(tile0 + p.tiles_per_block, p.tiles_total);
@@ -128,10 +173,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     int xpos[MAXP];          // global input position of each halo slot (-1 = zero padding) of the tile in flight
     unsigned dok = 0;        // validity bits of the 8 dY rows of the tile in flight
     int n_cur = 0;
-    const int dpiece = tid & 7;
-    const bool dch_ok = (co0 + dpiece * PE) < p.dyw;
 
-    auto issue = [&](int tl) {
+    int base = 0, dbase = 0, gd_base = 0, gh_base = 0, gw_base = 0;   // wave-uniform tile origin (scalar unit)
+    bool full = true;
+    auto decode = [&](int tl) {
         int t = tl;
         const int tw_i = t % p.tiles_w; t /= p.tiles_w;
         const int th_i = t % p.tiles_h; t /= p.tiles_h;
@@ -139,81 +184,116 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
         const int n = t / p.tiles_d;
         n_cur = n;
         const int od0 = td_i * p.TD, oh0 = th_i * p.TH, ow0 = tw_i * p.TW;
-        const int gd_base = od0 - (KD / 2), gh_base = oh0 * p.sh - (KH / 2), gw_base = ow0 * p.sw - (KW / 2);
+        gd_base = od0 - (KD / 2); gh_base = oh0 * p.sh - (KH / 2); gw_base = ow0 * p.sw - (KW / 2);
+        base = ((n * p.D + gd_base) * p.H + gh_base) * p.W + gw_base;
+        dbase = ((n * p.Do + od0) * p.Ho + oh0) * p.Wo + ow0;
+        full = od0 + p.TD <= p.Do && oh0 + p.TH <= p.Ho && ow0 + p.TW <= p.Wo;
+    };
+    auto issue_x = [&](auto LO, auto HI) {
 #pragma unroll
-        for (int i = 0; i < MAXP; ++i) {
+        for (int i = decltype(LO)::value; i < decltype(HI)::value; ++i) {
             const int id = sdec[i] >> 20, ih = (sdec[i] >> 10) & 1023, iw = sdec[i] & 1023;
-            const int gd = gd_base + id, gh = gh_base + ih, gw = gw_base + iw;
-            const bool ok = sdec[i] >= 0 && gd >= 0 && gd < p.D && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
-            const int pos = ok ? ((n * p.D + gd) * p.H + gh) * p.W + gw : 0;
+            const bool ok = (sdec[i] >= 0) & ((unsigned)(gd_base + id) < (unsigned)p.D) & ((unsigned)(gh_base + ih) < (unsigned)p.H) &
+                            ((unsigned)(gw_base + iw) < (unsigned)p.W);
+            const int rel = KEEP_REL ? srel[KEEP_REL ? i : 0] : (id * p.H + ih) * p.W + iw;
+            const int pos = ok ? base + rel : 0;
             xpos[i] = ok ? pos : -1;
-            xv[i] = *reinterpret_cast<const uint4*>(src + ((size_t)pos * cs + csrc) * sizeof(T) + piece * 16);
-        }
-        dok = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = (tid >> 3) + 32 * i;
-            const int pw = row & (p.TW - 1), ph = (row >> p.lgTW) & (p.TH - 1), pd = row >> (p.lgTW + p.lgTH);
-            const int od = od0 + pd, oh = oh0 + ph, ow = ow0 + pw;
-            const bool ok = od < p.Do && oh < p.Ho && ow < p.Wo && dch_ok;
-            const size_t L = ok ? ((((size_t)n * p.Do + od) * p.Ho + oh) * p.Wo + ow) : 0;
-            dok |= (ok ? 1u : 0u) << i;
-            dv[i] = *reinterpret_cast<const uint4*>(p.dy + (L * p.dyw + (dch_ok ? co0 + dpiece * PE : 0)) * sizeof(T));
+            xv[i] = *reinterpret_cast<const uint4*>(src + (size_t)pos * cs * sizeof(T));
         }
     };
-
-    constexpr bool PF = (MAXP <= 10);      // big-halo (strided) variant: no cross-tile prefetch, it would spill
-    if (PF && tile0 < tile1) issue(tile0);
-    for (int tl = tile0; tl < tile1; ++tl) {
-        if constexpr (!PF) issue(tl);
-        __syncthreads();   // previous tile's fragments consumed
-        // ---- input halo chunk (prologue applied, zero padding after the activation) and dY tile -> LDS
+    auto issue_dy = [&]() {
+        if (full) {
+            dok = dch_ok ? 0xFFu : 0u;
 #pragma unroll
-        for (int i = 0; i < MAXP; ++i) {
-            if (sdec[i] >= 0) {
-                uint4 u = xpos[i] >= 0 ? xv[i] : make_uint4(0u, 0u, 0u, 0u);
-                if (p.pre_a != nullptr && xpos[i] >= 0) {
+            for (int i = 0; i < 8; ++i)
+                dv[i] = *reinterpret_cast<const uint4*>(dsrc + (size_t)(dch_ok ? dbase + drel[i] : 0) * p.dyw * sizeof(T));
+        } else {
+            const int od_lim = p.Do - (gd_base + KD / 2), oh_lim = p.Ho - (gh_base + KH / 2) / p.sh, ow_lim = p.Wo - (gw_base + KW / 2) / p.sw;
+            dok = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int pd = ddec[i] >> 20, ph = (ddec[i] >> 10) & 1023, pw = ddec[i] & 1023;
+                const bool ok = (pd < od_lim) & (ph < oh_lim) & (pw < ow_lim) & dch_ok;
+                dok |= (ok ? 1u : 0u) << i;
+                dv[i] = *reinterpret_cast<const uint4*>(dsrc + (size_t)(ok ? dbase + drel[i] : 0) * p.dyw * sizeof(T));
+            }
+        }
+    };
+    // halo chunk (prologue applied, zero padding after the activation) -> LDS
+    auto store_x = [&](auto LO, auto HI) {
+#pragma unroll
+        for (int i = decltype(LO)::value; i < decltype(HI)::value; ++i) {
+            uint4 u = xpos[i] >= 0 ? xv[i] : make_uint4(0u, 0u, 0u, 0u);
+            if (p.pre_a != nullptr) {
+                if (xpos[i] >= 0) {
                     const int smp = (KD == 3) ? n_cur : (int)((unsigned)xpos[i] / (unsigned)p.S_in);
                     const size_t co = (size_t)smp * p.cin + c + piece * PE;
                     u = apply_pre<T>(u, p.pre_a + co, p.pre_b + co, p.pre_silu);
                 }
-                const int hp = (tid >> 2) + 64 * i;
-                *reinterpret_cast<uint4*>(halo + hp * PITCH + piece * 16) = u;
             }
+            const int hp = (tid >> 2) + 64 * i;
+            *reinterpret_cast<uint4*>(halo + hp * XP + piece * 16) = u;
         }
+    };
+    auto store_dy = [&]() {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = (tid >> 3) + 32 * i;
             const uint4 u = ((dok >> i) & 1u) ? dv[i] : make_uint4(0u, 0u, 0u, 0u);
-            *reinterpret_cast<uint4*>(dyt + row * DY_PITCH + dpiece * 16) = u;
+            *reinterpret_cast<uint4*>(dyt + row * DYP + ((dpiece * 16) ^ dy_swz(row))) = u;
         }
-        __syncthreads();
-        if constexpr (PF) issue(min(tl + 1, tile1 - 1));   // next tile's loads fly under this tile's MFMAs (last: harmless re-read)
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using IH = std::integral_constant<int, MAXP / 2>;
+    using IM = std::integral_constant<int, MAXP>;
+
+    constexpr bool PF = (MAXP <= 10);      // big-halo (strided) variant: no cross-tile prefetch, it would spill
+    if (PF && tile0 < tile1) {
+        decode(tile0);
+        issue_x(I0{}, IM{});
+        issue_dy();
+    }
+    for (int tl = tile0; tl < tile1; ++tl) {
+        if constexpr (PF) {
+            __syncthreads();   // previous tile's fragments consumed
+            store_x(I0{}, IM{});
+            store_dy();
+            __syncthreads();
+            // next tile's loads fly under this tile's MFMAs (last: harmless re-read)
+            decode(min(tl + 1, tile1 - 1));
+            issue_x(I0{}, IM{});
+            issue_dy();
+        } else {
+            decode(tl);
+            issue_x(I0{}, IH{});
+            issue_dy();
+            __syncthreads();
+            store_x(I0{}, IH{});
+            store_dy();
+            issue_x(IH{}, IM{});
+            store_x(IH{}, IM{});
+            __syncthreads();
+        }
 
         // ---- reduce this tile's positions
         if constexpr (IS_BF16) {
-            const int ks0 = TAPSPLIT ? 0 : wave * 4;
-            const int ks1 = TAPSPLIT ? 16 : wave * 4 + 4;
-#pragma unroll 2
-            for (int ks = ks0; ks < ks1; ++ks) {
-                // k rows of this lane: position index 16*ks + 8*half' + 4*t + q with half' = grp>>1
-                int xr[2], ar[2];
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const int pp = 16 * ks + 8 * (grp >> 1) + 4 * tt + q;
-                    const int pw = pp & (p.TW - 1), ph = (pp >> p.lgTW) & (p.TH - 1), pd = pp >> (p.lgTW + p.lgTH);
-                    xr[tt] = ((pd * p.IH + ph * p.sh) * p.IW + pw * p.sw) * PITCH + colb * 2;
-                    ar[tt] = pp * DY_PITCH + colb * 2;
-                }
+            auto kstep = [&](int j, int xr0, int xr1) {
                 uint4 a[MT];
 #pragma unroll
-                for (int mi = 0; mi < MT; ++mi) a[mi] = tr_frag(dyt, ar[0] + mi * 64, ar[1] + mi * 64);
+                for (int mi = 0; mi < MT; ++mi) a[mi] = tr_frag(dyt, arow[mi] + j * 16 * DYP, arow[mi] + (j * 16 + 4) * DYP);
 #pragma unroll
                 for (int ti = 0; ti < TPW; ++ti) {
-                    const uint4 b = tr_frag(halo, xr[0] + tapoff[ti], xr[1] + tapoff[ti]);
+                    const uint4 b = tr_frag(halo, xr0 + tapoff[ti], xr1 + tapoff[ti]);
 #pragma unroll
                     for (int mi = 0; mi < MT; ++mi) mma_step<T>(a[mi], b, acc[ti][mi]);
                 }
+            };
+            if constexpr (KEEP_REL) {
+#pragma unroll
+                for (int j = 0; j < NKS; ++j) kstep(j, xrow[j][0], xrow[j][1]);
+            } else {
+#pragma unroll 2
+                for (int j = 0; j < NKS; ++j) kstep(j, xrow_of(j, 0), xrow_of(j, 1));   // rolled: keeps the decode out of registers
             }
         } else {
             // exact f32: k = position pair (2*kk + half); lanes with ci >= 16 contribute zeros
@@ -223,11 +303,11 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
             for (int kk = kk0; kk < kk1; ++kk) {
                 const int pp = 2 * kk + half;
                 const int pw = pp & (p.TW - 1), ph = (pp >> p.lgTW) & (p.TH - 1), pd = pp >> (p.lgTW + p.lgTH);
-                const float av = *reinterpret_cast<const float*>(dyt + pp * DY_PITCH + col * 4);
-                const int xrow = ((pd * p.IH + ph * p.sh) * p.IW + pw * p.sw) * PITCH + (col & 15) * 4;
+                const float av = *reinterpret_cast<const float*>(dyt + pp * DYP + ((col * 4) ^ dy_swz(pp)));
+                const int xr = ((pd * p.IH + ph * p.sh) * p.IW + pw * p.sw) * XP + (col & 15) * 4;
 #pragma unroll
                 for (int ti = 0; ti < TPW; ++ti) {
-                    float bv = *reinterpret_cast<const float*>(halo + xrow + tapoff[ti]);
+                    float bv = *reinterpret_cast<const float*>(halo + xr + tapoff[ti]);
                     bv = (col < 16) ? bv : 0.0f;
                     acc[ti][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[ti][0], 0, 0, 0);
                 }
@@ -333,7 +413,7 @@ extern "C" int rho_conv_nd_wgrad(const rho_conv_desc* dp, const void* dy, int64_
     k.S_in = (long long)d.d * d.h * d.w_;
 
     const size_t lds_cap = 160 * 1024;
-    int np_cap = (int)((lds_cap - 256 * DY_PITCH) / PITCH);
+    int np_cap = (int)((lds_cap - 256 * DYP) / XP);
     if (np_cap > 28 * 64) np_cap = 28 * 64;
     TileChoice t = choose_tile(d, k.D, k.Do, k.Ho, k.Wo, 640);
     if (!t.ok) t = choose_tile(d, k.D, k.Do, k.Ho, k.Wo, np_cap);
@@ -359,8 +439,8 @@ extern "C" int rho_conv_nd_wgrad(const rho_conv_desc* dp, const void* dy, int64_
     splits = cdiv(k.tiles_total, k.tiles_per_block);
     if (cdiv(d.coutp, COT) > 65535 || cin / CK > 65535) return RHO_E_SHAPE;
     dim3 grid((unsigned)splits, (unsigned)cdiv(d.coutp, COT), (unsigned)(cin / CK));
-    const size_t lds = (size_t)t.NP * PITCH + 256 * DY_PITCH;
     const int maxp = cdiv(t.NP, 64);
+    const size_t lds = (size_t)(maxp <= 10 ? 10 : 28) * 64 * XP + 256 * DYP;
     hipStream_t st = as_stream(stream);
     if (d.dtype == RHO_BF16) return launch_wgrad_taps<bf16_raw>(d, k, maxp, grid, lds, st);
     return launch_wgrad_taps<float>(d, k, maxp, grid, lds, st);

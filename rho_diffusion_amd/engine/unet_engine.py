@@ -463,9 +463,9 @@ class _Plan:
         def key(t: Tensor) -> int:
             return t.data_ptr()
 
-        def emit(fn, kind, flops=0.0, nbytes=0.0):
+        def emit(fn, kind, flops=0.0, nbytes=0.0, **shape):
             bw.append(fn)
-            binfo.append(dict(kind=kind, flops=flops, bytes=nbytes))
+            binfo.append(dict(kind=kind, flops=flops, bytes=nbytes, **shape))
 
         def gradbuf(t: Tensor):
             """(buffer, accumulate?) for a write into the gradient of activation t."""
@@ -518,19 +518,33 @@ class _Plan:
                 emit(lambda s, a=a: L.rho_upsample2x(*a, s), "upsample", nbytes=5.0 * esz * x1.numel())
                 x1 = tmp_up
             pre = node["pre"]
-            d = ops.make_conv_desc(x1, node["x2"], cw.w, cw.b, kernel=cw.kernel, cout=cw.cout, split=cw.cout, y=dY, y2=None,
-                                   stride_hw=node["stride_hw"], pre_a=pre["a"] if pre else None, pre_b=pre["b"] if pre else None,
-                                   pre_silu=node["pre_silu"])
+            x2 = node["x2"]
+            xact = None
+            if pre is not None:
+                # materialise act(a*x+b) once (HBM-rate) instead of redoing it in every (cout tile, cin chunk) workgroup
+                c1_ = x1.shape[-1]
+                c2_ = x2.shape[-1] if x2 is not None else 0
+                xact = pool.get(tuple(x1.shape[:4]) + (c1_ + c2_,), dt)
+                Nn = x1.shape[0]
+                Sx = x1.shape[1] * x1.shape[2] * x1.shape[3]
+                a = (ptr(x1), c1_, ptr(x2), c2_, dtc, Nn, Sx, ptr(pre["a"]), ptr(pre["b"]), int(node["pre_silu"]), ptr(xact))
+                emit(lambda s, a=a: L.rho_gn_apply(*a, s), "gn_apply", nbytes=2.0 * esz * xact.numel())
+                x1, x2 = xact, None
+            d = ops.make_conv_desc(x1, x2, cw.w, cw.b, kernel=cw.kernel, cout=cw.cout, split=cw.cout, y=dY, y2=None,
+                                   stride_hw=node["stride_hw"], pre_silu=False)
             self.keep.append(d)
             nw = cw.taps * cw.coutp * cw.cinp
             dwv = dwbuf[:nw]
             emit(lambda s, t=dwv: (t.zero_(), 0)[1], "memset", nbytes=4.0 * nw)
             emit(lambda s, d=d, dy=ptr(dY), w_=dyw: L.rho_conv_nd_wgrad(C.byref(d), dy, w_, ptr(dwbuf), s), "wgrad",
-                 flops=2.0 * N * S * cw.cout * cw.cin * cw.taps, nbytes=float(esz) * (x1.numel() + dY.numel()))
+                 flops=2.0 * N * S * cw.cout * cw.cin * cw.taps, nbytes=float(esz) * (x1.numel() + dY.numel()),
+                 cin=cw.cin, cout=cw.cout, taps=cw.taps, positions=N * S)
             emit(lambda s, cw=cw, rs=rs: L.rho_wgrad_finalize(ptr(dwbuf), pgrad(cw.weight), cw.cout, cw.cin, cw.taps, cw.coutp,
                                                               cw.cinp, rs, 1, s), "wgrad_finalize", nbytes=8.0 * nw)
             if tmp_up is not None:
                 pool.put(tmp_up)
+            if xact is not None:
+                pool.put(xact)
 
         def dgrad(node, dY: Tensor, dyw: int):
             cw = node["cw"]
