@@ -207,10 +207,24 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
         }                                                                                               \
     } while (0)
 
-    // prologue: steps 0 .. PD-1 of chunk 0 in flight (PD <= NS), step 0 landed in LDS slot 0
+    // Pipelined variant (3 | NS, i.e. every kernel with more than one tap): a 3-slot LDS weight ring, slot = step % 3.
+    // Step q's tile is fetched at step q-4, handed to LDS at the end of step q-2 (two steps in flight) and read from
+    // step q-1 on, i.e. one barrier AFTER it was written - so the fragment reads of step q+1 can be issued while
+    // step q's MFMAs run, instead of right after the barrier with every wave of the workgroup waiting on them.
+    constexpr bool PIPE = (NS % 3 == 0) && (G == 1);
+    if constexpr (PIPE) {
+        RHO_LOAD_W(0, 0, 0);
+        RHO_LOAD_W(1, 0, 1);
+        RHO_LOAD_W(2, 0, 2);
+        RHO_STORE_W(0, 0);
+        RHO_STORE_W(1, 1);
+        RHO_LOAD_W(0, (3 < NS) ? 0 : min(1, nck - 1), 3 % NS);
+    } else {
+        // steps 0 .. PD-1 of chunk 0 in flight (PD <= NS), step 0 landed in LDS slot 0
 #pragma unroll
-    for (int i = 0; i < PD; ++i) RHO_LOAD_W(i, 0, i);
-    RHO_STORE_W(0, 0);
+        for (int i = 0; i < PD; ++i) RHO_LOAD_W(i, 0, i);
+        RHO_STORE_W(0, 0);
+    }
     int cur = 0;
 
     // Halo staging.  HPF (one workgroup per CU, nothing else to hide behind): the NEXT chunk's global loads are
@@ -294,53 +308,98 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
         }
         __syncthreads();
 
-        // ---- all taps out of the resident tile, G taps per barrier step
-#pragma unroll
-        for (int st = 0; st < NS; ++st) {
-            const bool has_next = !(ck == nck - 1 && st == NS - 1);
-            // step q = ck*NS + st: its register set (st % PD) went to LDS one step ago -> refill it with step q + PD
-            // now, so the fetch has PD steps of MFMA work to hide under; at the end of this step, step q + 1 (fetched
-            // PD - 1 steps ago) is handed to the other LDS slot.  Unconditional (past the end it re-reads the last
-            // chunk's tiles) so that the number of loads in flight is static and the compiler waits with a counted
-            // vmcnt instead of draining to 0.
-            {
-                const int nst = (st + PD < NS) ? st + PD : st + PD - NS;
-                const int nckk = (st + PD < NS) ? ck : min(ck + 1, nck - 1);
-                RHO_LOAD_W(st % PD, nckk, nst);
-            }
-            // next chunk's halo: issued AFTER this step's weight fetch (vmcnt retires in order, so the counted waits
-            // for the next PD-1 steps' weights do not drain these loads) and unconditionally (static count)
-            if constexpr (HPF) {
-                if (st * G == TPF) {
-                    __builtin_amdgcn_sched_barrier(0);     // keep the halo loads younger than the weight fetch above
-                    RHO_HALO_LOAD(min(ck + 1, nck - 1));
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const int tap = st * G + g;
+        if constexpr (PIPE) {
+            // fragments: X = k-half 0 of the current step (already in flight), Y = k-half 1
+            uint4 xa[MT], xb[2], ya[MT], yb[2];
+            auto frag_reads = [&](int tap, int slot, int s_, uint4 (&fa)[MT], uint4 (&fb)[2]) {
                 const int kd = tap / (KH * KW), kh = (tap / KW) % KH, kw = tap % KW;
-                const char* wcur = wbuf + (size_t)cur * SLOT + g * BM * PITCH + a_off;
-                const int dtap = kd * p.IH * p.IW * PITCH;
-                const char* b0p = halo + (dtap + offd[0] + offh[0][kh] + offw[0][kw]);
-                const char* b1p = halo + (dtap + offd[1] + offh[1][kh] + offw[1][kw]);
+                const char* wcur = wbuf + (size_t)slot * SLOT + a_off + 32 * s_;
+                const int dtap = kd * p.IH * p.IW * PITCH + 32 * s_;
+                fb[0] = *reinterpret_cast<const uint4*>(halo + (dtap + offd[0] + offh[0][kh] + offw[0][kw]));
+                fb[1] = *reinterpret_cast<const uint4*>(halo + (dtap + offd[1] + offh[1][kh] + offw[1][kw]));
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const uint4 b0 = *reinterpret_cast<const uint4*>(b0p + 32 * s);
-                    const uint4 b1 = *reinterpret_cast<const uint4*>(b1p + 32 * s);
+                for (int mi = 0; mi < MT; ++mi) fa[mi] = *reinterpret_cast<const uint4*>(wcur + mi * 32 * PITCH);
+            };
+            frag_reads(0, 0, 0, xa, xb);
 #pragma unroll
-                    for (int mi = 0; mi < MT; ++mi) {
-                        const uint4 a = *reinterpret_cast<const uint4*>(wcur + mi * 32 * PITCH + 32 * s);
-                        mma_step<T>(a, b0, acc[mi][0]);
-                        mma_step<T>(a, b1, acc[mi][1]);
+            for (int st = 0; st < NS; ++st) {
+                {   // step st + 4 -> register set (st + 1) % 3 (its previous tile went to LDS at the end of step st - 1);
+                    // unconditional and clamped, so the loads in flight are a static count (counted vmcnt, no drain)
+                    const int nst = (st + 4) % NS;
+                    const int nckk = min(ck + (st + 4) / NS, nck - 1);
+                    RHO_LOAD_W((st + 1) % 3, nckk, nst);
+                }
+                if constexpr (HPF) {
+                    if (st == TPF) {
+                        __builtin_amdgcn_sched_barrier(0);     // keep the halo loads younger than the weight fetch above
+                        RHO_HALO_LOAD(min(ck + 1, nck - 1));
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+                frag_reads(st, st % 3, 1, ya, yb);
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) {
+                    mma_step<T>(xa[mi], xb[0], acc[mi][0]);
+                    mma_step<T>(xa[mi], xb[1], acc[mi][1]);
+                }
+                if (st + 1 < NS) frag_reads(st + 1, (st + 1) % 3, 0, xa, xb);   // next chunk's first step: after its halo is staged
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) {
+                    mma_step<T>(ya[mi], yb[0], acc[mi][0]);
+                    mma_step<T>(ya[mi], yb[1], acc[mi][1]);
+                }
+                RHO_STORE_W((st + 2) % 3, (st + 2) % 3);       // step st + 2 (slot last read in step st - 1)
+                __syncthreads();
             }
-            if (has_next) RHO_STORE_W(cur ^ 1, (st + 1) % PD);
-            __syncthreads();
-            cur ^= 1;
-        }
+        } else {
+            // ---- all taps out of the resident tile, G taps per barrier step
+    #pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                const bool has_next = !(ck == nck - 1 && st == NS - 1);
+                // step q = ck*NS + st: its register set (st % PD) went to LDS one step ago -> refill it with step q + PD
+                // now, so the fetch has PD steps of MFMA work to hide under; at the end of this step, step q + 1 (fetched
+                // PD - 1 steps ago) is handed to the other LDS slot.  Unconditional (past the end it re-reads the last
+                // chunk's tiles) so that the number of loads in flight is static and the compiler waits with a counted
+                // vmcnt instead of draining to 0.
+                {
+                    const int nst = (st + PD < NS) ? st + PD : st + PD - NS;
+                    const int nckk = (st + PD < NS) ? ck : min(ck + 1, nck - 1);
+                    RHO_LOAD_W(st % PD, nckk, nst);
+                }
+                // next chunk's halo: issued AFTER this step's weight fetch (vmcnt retires in order, so the counted waits
+                // for the next PD-1 steps' weights do not drain these loads) and unconditionally (static count)
+                if constexpr (HPF) {
+                    if (st * G == TPF) {
+                        __builtin_amdgcn_sched_barrier(0);     // keep the halo loads younger than the weight fetch above
+                        RHO_HALO_LOAD(min(ck + 1, nck - 1));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+    #pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int tap = st * G + g;
+                    const int kd = tap / (KH * KW), kh = (tap / KW) % KH, kw = tap % KW;
+                    const char* wcur = wbuf + (size_t)cur * SLOT + g * BM * PITCH + a_off;
+                    const int dtap = kd * p.IH * p.IW * PITCH;
+                    const char* b0p = halo + (dtap + offd[0] + offh[0][kh] + offw[0][kw]);
+                    const char* b1p = halo + (dtap + offd[1] + offh[1][kh] + offw[1][kw]);
+    #pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const uint4 b0 = *reinterpret_cast<const uint4*>(b0p + 32 * s);
+                        const uint4 b1 = *reinterpret_cast<const uint4*>(b1p + 32 * s);
+    #pragma unroll
+                        for (int mi = 0; mi < MT; ++mi) {
+                            const uint4 a = *reinterpret_cast<const uint4*>(wcur + mi * 32 * PITCH + 32 * s);
+                            mma_step<T>(a, b0, acc[mi][0]);
+                            mma_step<T>(a, b1, acc[mi][1]);
+                        }
+                    }
+                }
+                if (has_next) RHO_STORE_W(cur ^ 1, (st + 1) % PD);
+                __syncthreads();
+                cur ^= 1;
+            }
+            }
     }
 
 #undef RHO_LOAD_W
@@ -534,9 +593,8 @@ extern "C" int rho_conv_nd_fwd(const rho_conv_desc* dp, void* stream) {
 
     const size_t lds_cap = 160 * 1024;
     const int taps = d.kd * d.kh * d.kw;
-    const int G = 1;                                            // taps per weight-ring slot (matches the kernel)
-    (void)taps;
-    int np_cap = (int)((lds_cap - 2 * (size_t)G * BM * PITCH) / PITCH);
+    const int WSLOTS = (taps % 3 == 0) ? 3 : 2;                 // LDS weight-ring depth (matches the kernel's PIPE)
+    int np_cap = (int)((lds_cap - (size_t)WSLOTS * BM * PITCH) / PITCH);
     if (np_cap > 28 * 64) np_cap = 28 * 64;
     // prefer the small-halo (2 blocks / CU) configuration when it exists
     TileChoice t = choose_tile(d, k.D, k.Do, k.Ho, k.Wo, 640);
@@ -567,7 +625,7 @@ extern "C" int rho_conv_nd_fwd(const rho_conv_desc* dp, void* stream) {
     const long long tiles = (long long)cdiv(k.Do, t.TD) * k.tiles_h * k.tiles_w;
     if (tiles > 0x7FFFFFFFLL || d.coutp / BM > 65535 || gridz > 65535) return RHO_E_SHAPE;
     dim3 grid((unsigned)tiles, (unsigned)(d.coutp / BM), (unsigned)gridz);
-    const size_t lds = (size_t)t.NP * PITCH + 2 * (size_t)G * BM * PITCH;
+    const size_t lds = (size_t)t.NP * PITCH + (size_t)WSLOTS * BM * PITCH;
     hipStream_t st = as_stream(stream);
     if (d.dtype == RHO_BF16) return launch_taps<bf16_raw>(d, k, BM, t.NP, grid, lds, st);
     return launch_taps<float>(d, k, BM, t.NP, grid, lds, st);
