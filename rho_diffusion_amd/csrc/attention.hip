@@ -17,7 +17,7 @@
 #include "common.h"
 
 template <int CH, int KT>  // KT keys per LDS tile (64; 32 for CH = 256 to stay inside static LDS)
-__global__ __launch_bounds__(256) void k_attn_bf16(const bf16_raw* __restrict__ qk, const bf16_raw* __restrict__ vt,
+__global__ __launch_bounds__(256, CH <= 128 ? 2 : 1) void k_attn_bf16(const bf16_raw* __restrict__ qk, const bf16_raw* __restrict__ vt,
                                                    bf16_raw* __restrict__ out, int T, int C, float scale_log2e,
                                                    float* __restrict__ lse) {
     constexpr int KP = CH * 2 + 16;   // K tile row pitch (bytes): odd number of 16-B slots => conflict-free
@@ -54,80 +54,124 @@ __global__ __launch_bounds__(256) void k_attn_bf16(const bf16_raw* __restrict__ 
     const int prow = (col & 0x13) | ((col & 4) << 1) | ((col & 8) >> 1);
     const bool vec_v = ((T & 7) == 0);
 
+    // staging addresses: thread -> (row, 16-byte piece), fixed for the whole key walk; only the tile origin moves
+    constexpr int KPC = CH / 8;                   // 16-byte pieces per K row
+    constexpr int KIT = (KT * KPC + 255) / 256;   // K pieces per thread
+    constexpr bool KEXACT = (KIT * 256 == KT * KPC);
+    constexpr int VPC = KT / 8;                   // 16-byte pieces per V^T row
+    constexpr int VIT = (NCT * 32 * VPC + 255) / 256;
+    const bf16_raw* const kbase = qk + (size_t)b * T * row2c + C + (size_t)h * CH;
+    const bf16_raw* const vbase = vt + ((size_t)b * C + (size_t)h * CH) * T;
+    // m_run is kept in the scaled base-2 domain; the logits stay raw and are scaled inside the exponent's FMA
+    const float sc = scale_log2e;
+
     for (int kt0 = 0; kt0 < T; kt0 += KT) {
         __syncthreads();  // previous tile fully consumed
         // ---- stage K tile [KT keys][CH] and V^T tile [CH][KT keys]
-        for (int pc = tid; pc < KT * (CH / 8); pc += 256) {
-            const int key = pc / (CH / 8), piece = pc % (CH / 8);
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (kt0 + key < T)
-                v = *reinterpret_cast<const uint4*>(qk + ((size_t)b * T + kt0 + key) * row2c + C + (size_t)h * CH + piece * 8);
-            *reinterpret_cast<uint4*>(k_lds + key * KP + piece * 16) = v;
-        }
-        if (vec_v) {
-            for (int pc = tid; pc < NCT * 32 * (KT / 8); pc += 256) {
-                const int c = pc / (KT / 8), piece = pc % (KT / 8);
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (c < CH && kt0 + piece * 8 < T)  // T % 8 == 0: a piece is entirely in or out
-                    v = *reinterpret_cast<const uint4*>(vt + ((size_t)b * C + (size_t)h * CH + c) * T + kt0 + piece * 8);
-                *reinterpret_cast<uint4*>(v_lds + c * VP + piece * 16) = v;
+        {
+            uint4 kv[KIT];
+#pragma unroll
+            for (int i = 0; i < KIT; ++i) {
+                const int pc = tid + 256 * i;
+                const int key = pc / KPC, piece = pc % KPC;
+                const int kc = min(kt0 + (KEXACT ? key : min(key, KT - 1)), T - 1);   // clamped, zeroed below: branch-free loads
+                kv[i] = *reinterpret_cast<const uint4*>(kbase + (size_t)kc * row2c + piece * 8);
             }
-        } else {
-            for (int e = tid; e < NCT * 32 * KT; e += 256) {
-                const int c = e / KT, key = e % KT;
-                bf16_raw v = 0;
-                if (c < CH && kt0 + key < T) v = vt[((size_t)b * C + (size_t)h * CH + c) * T + kt0 + key];
-                *reinterpret_cast<bf16_raw*>(v_lds + c * VP + key * 2) = v;
+            if (vec_v) {
+                uint4 vv[VIT];
+#pragma unroll
+                for (int i = 0; i < VIT; ++i) {
+                    const int pc = tid + 256 * i;
+                    const int c = pc / VPC, piece = pc % VPC;
+                    const bool ok = (VIT * 256 == NCT * 32 * VPC || pc < NCT * 32 * VPC) && c < CH && kt0 + piece * 8 < T;
+                    vv[i] = *reinterpret_cast<const uint4*>(vbase + (size_t)(ok ? c : 0) * T + (ok ? kt0 + piece * 8 : 0));
+                    if (!ok) vv[i] = make_uint4(0u, 0u, 0u, 0u);
+                }
+#pragma unroll
+                for (int i = 0; i < VIT; ++i) {
+                    const int pc = tid + 256 * i;
+                    const int c = pc / VPC, piece = pc % VPC;
+                    if (VIT * 256 == NCT * 32 * VPC || pc < NCT * 32 * VPC) *reinterpret_cast<uint4*>(v_lds + c * VP + piece * 16) = vv[i];
+                }
+            } else {
+                for (int e = tid; e < NCT * 32 * KT; e += 256) {
+                    const int c = e / KT, key = e % KT;
+                    bf16_raw v = 0;
+                    if (c < CH && kt0 + key < T) v = vbase[(size_t)c * T + kt0 + key];
+                    *reinterpret_cast<bf16_raw*>(v_lds + c * VP + key * 2) = v;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < KIT; ++i) {
+                const int pc = tid + 256 * i;
+                const int key = pc / KPC, piece = pc % KPC;
+                if (KEXACT || pc < KT * KPC)
+                    *reinterpret_cast<uint4*>(k_lds + key * KP + piece * 16) = (kt0 + key < T) ? kv[i] : make_uint4(0u, 0u, 0u, 0u);
             }
         }
         __syncthreads();
 
-        // ---- S^T for the two 32-key sub-tiles
+        // ---- S^T for the 32-key sub-tiles
         f32x16_t s[NU];
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[u][r] = 0.0f;
             const char* kp = k_lds + (32 * u + prow) * KP + 16 * half;
+            // K fragments in groups of 4 reads ahead of their MFMAs (one read per MFMA, waited for right before it,
+            // leaves the LDS latency exposed 2 * NKK times per tile)
+            constexpr int KG = NKK < 4 ? NKK : 4;
 #pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
-                const uint4 a = *reinterpret_cast<const uint4*>(kp + 32 * kk);
-                s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, qf[kk]),
-                                                              s[u], 0, 0, 0);
+            for (int k0 = 0; k0 < NKK; k0 += KG) {
+                uint4 a[KG];
+#pragma unroll
+                for (int g = 0; g < KG; ++g) a[g] = *reinterpret_cast<const uint4*>(kp + 32 * (k0 + g));
+#pragma unroll
+                for (int g = 0; g < KG; ++g)
+                    s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[g]),
+                                                                  __builtin_bit_cast(bf16x8_t, qf[k0 + g]), s[u], 0, 0, 0);
             }
         }
-        // ---- online softmax (base-2), masking keys >= T
-        float mx = -INFINITY;
+        // ---- online softmax (base-2).  Only the last, partial tile needs the key mask (uniform branch).
+        if (kt0 + KT > T) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;               // accumulator row
+                    const int krow = (row & 0x13) | ((row & 4) << 1) | ((row & 8) >> 1);  // key held there (pi)
+                    if (kt0 + 32 * u + krow >= T) s[u][r] = -INFINITY;
+                }
+        }
+        float mx = s[0][0];
 #pragma unroll
         for (int u = 0; u < NU; ++u)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;               // accumulator row
-                const int krow = (row & 0x13) | ((row & 4) << 1) | ((row & 8) >> 1);  // key held there (pi)
-                const int key = kt0 + 32 * u + krow;
-                const float v = (key < T) ? s[u][r] * scale_log2e : -INFINITY;
-                s[u][r] = v;
-                mx = fmaxf(mx, v);
-            }
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[u][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);  // m_run = -inf on the first tile -> 0
+        const float m_new = fmaxf(m_run, mx * sc);          // sc > 0: max commutes with the scaling
+        // the running maximum stops moving after the first few tiles: rescale only when some query of this wave
+        // saw a new maximum (alpha == 1 exactly otherwise, so skipping is bit-identical)
+        if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+            const float alpha = exp2f(m_run - m_new);       // m_run = -inf on the first tile -> 0
+            l_run *= alpha;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+            m_run = m_new;
+        }
         float ps = 0.0f;
 #pragma unroll
         for (int u = 0; u < NU; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(s[u][r] - m_new);
+                const float pv = __builtin_amdgcn_exp2f(fmaf(s[u][r], sc, -m_run));
                 s[u][r] = pv;
                 ps += pv;
             }
         ps += __shfl_xor(ps, 32, 64);
-        l_run = l_run * alpha + ps;
-        m_run = m_new;
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+        l_run += ps;
 
         // ---- O^T += V^T * P^T : P accumulator registers 8s..8s+7 are k-step s of the B operand
 #pragma unroll

@@ -189,6 +189,7 @@ CONV_CASES = [
     ("1d_up", 1, 2, 32, 0, 32, (16,), 3, 1, True, False, False),
     ("1d_1x1", 1, 2, 64, 0, 192, (16,), 1, 1, False, True, True),
     ("3d_big_tile", 3, 1, 64, 0, 64, (8, 16, 16), 3, 1, False, True, True),
+    ("3d_tile512_ragged", 3, 2, 64, 32, 64, (9, 10, 13), 3, 1, False, True, True),     # 512-position tiles (bf16), ragged edges
 ]
 
 
