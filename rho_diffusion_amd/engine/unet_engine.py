@@ -356,12 +356,9 @@ class _Plan:
             N, Do, Ho, Wo = ops.conv_out_shape(x1.shape, cw.kernel, stride_hw, up_hw)
             y = buf(N, Do, Ho, Wo, split_) if split_ > 0 else None
             y2 = buf(N, cout - split_, Do * Ho * Wo, dtype=y2_dtype or dt) if split_ < cout else None
-            import os as _os   # EXPERIMENT (timing only, wrong results)
-            _pre = None if _os.environ.get("RHO_EXP_NOPRE") else pre
-            _silu = False if _os.environ.get("RHO_EXP_NOSILU") else pre_silu
             d = ops.make_conv_desc(x1, x2, cw.w, cw.b, kernel=cw.kernel, cout=cout, split=split_, y=y, y2=y2,
-                                   stride_hw=stride_hw, up_hw=up_hw, pre_a=_pre["a"] if _pre else None,
-                                   pre_b=_pre["b"] if _pre else None, pre_silu=_silu, res=res, res_add=None)
+                                   stride_hw=stride_hw, up_hw=up_hw, pre_a=pre["a"] if pre else None,
+                                   pre_b=pre["b"] if pre else None, pre_silu=pre_silu, res=res, res_add=None)
             if res_add_off is not None:
                 d.res_add = self.film.data_ptr() + 4 * res_add_off
                 d.res_add_stride = self.film.shape[1]
