@@ -65,14 +65,32 @@ __global__ __launch_bounds__(256) void k_attn_delta(const T* __restrict__ o, con
     delta[(b_ * heads + h) * T_ + q] = acc;
 }
 
+// ------------------------------------------------------------------------------------------------ LDS tile layout
+// A [row][CH] bf16 tile is read two ways: whole 16-byte row pieces (ds_read_b128, 16 different rows per lane group)
+// and transposed 4-row x 64-byte windows (ds_read_b64_tr_b16, one half-wave = rows r..r+3 of one window).  A padded
+// pitch serves only one of them (odd 16-byte-slot pitch: b128 conflict-free, the 4 windows overlap 4-fold - PMC:
+// SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE in these kernels).  For CH = 128 the rows are therefore unpadded
+// (256 B = all 64 banks) and the 16-byte slot is XORed with a bit-permutation of the row index: bits 0-1 of the row
+// pick the 64-byte window (4 consecutive rows -> 4 windows: tr reads conflict-free), bits 2-3 the slot inside it
+// (any 16 rows distinct mod 16 -> 16 distinct slots: b128 reads conflict-free).
+template <int CH>
+struct RowTile {
+    static constexpr bool SWZ = (CH == 128);
+    static constexpr int P = SWZ ? 256 : CH * 2 + 16;
+    static __device__ __forceinline__ int swz(int row) { return SWZ ? ((((row & 3) << 2) | ((row >> 2) & 3)) << 4) : 0; }
+    // byte offset of 16-byte-aligned `byte` (may carry an 8-byte sub-offset) in `row`
+    static __device__ __forceinline__ int at(int row, int byte) { return row * P + (byte ^ swz(row)); }
+};
+
 // ------------------------------------------------------------------------------------------------ dQ (bf16)
 template <int CH, int KT>
-__global__ __launch_bounds__(256) void k_attn_dq(const bf16_raw* __restrict__ qk, const bf16_raw* __restrict__ vt,
+__global__ __launch_bounds__(256, CH <= 128 ? 2 : 1) void k_attn_dq(const bf16_raw* __restrict__ qk, const bf16_raw* __restrict__ vt,
                                                  const bf16_raw* __restrict__ dout, const float* __restrict__ lse,
                                                  const float* __restrict__ delta, bf16_raw* __restrict__ dqk, int T, int C,
                                                  float scale_log2e, float scale, int dqk_rs) {
-    constexpr int KP = CH * 2 + 16;
-    constexpr int VP = KT * 2 + 16;
+    using KL = RowTile<CH>;
+    constexpr int KP = KL::P;
+    constexpr int VP = (KT == 64) ? 192 : KT * 2 + 16;   // [ch][key] tile, transposing reads only: pitch = 64 (mod 256)
     constexpr int NKK = CH / 16;
     constexpr int NCT = (CH + 31) / 32;
     constexpr int NU = KT / 32;
@@ -95,8 +113,8 @@ __global__ __launch_bounds__(256) void k_attn_dq(const bf16_raw* __restrict__ qk
             dof[kk] = *reinterpret_cast<const uint4*>(dp + 16 * kk);
         }
     }
-    const float lse_q = lse[((size_t)b * heads + h) * T + qc];
-    const float del_q = delta[((size_t)b * heads + h) * T + qc];
+    const float nlse_q = -lse[((size_t)b * heads + h) * T + qc];
+    const float ndel_q = -delta[((size_t)b * heads + h) * T + qc] * scale;
 
     f32x16_t dq[NCT];
 #pragma unroll
@@ -108,29 +126,55 @@ __global__ __launch_bounds__(256) void k_attn_dq(const bf16_raw* __restrict__ qk
     const int pswap = (pp == 1) ? 2 : (pp == 2 ? 1 : pp);     // pi applied to the 4-column chunk a lane addresses
     const bool vec_v = ((T & 7) == 0);
 
+    constexpr int KPC = CH / 8;
+    constexpr int KIT = (KT * KPC + 255) / 256;
+    constexpr bool KEXACT = (KIT * 256 == KT * KPC);
+    constexpr int VPC = KT / 8;
+    constexpr int VIT = (NCT * 32 * VPC + 255) / 256;
+    constexpr bool VEXACT = (VIT * 256 == NCT * 32 * VPC);
+    const bf16_raw* const kbase = qk + (size_t)b * T * row2c + C + (size_t)h * CH;
+    const bf16_raw* const vbase = vt + ((size_t)b * C + (size_t)h * CH) * T;
+
     for (int kt0 = 0; kt0 < T; kt0 += KT) {
         __syncthreads();
-        for (int pc = tid; pc < KT * (CH / 8); pc += 256) {
-            const int key = pc / (CH / 8), piece = pc % (CH / 8);
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (kt0 + key < T)
-                v = *reinterpret_cast<const uint4*>(qk + ((size_t)b * T + kt0 + key) * row2c + C + (size_t)h * CH + piece * 8);
-            *reinterpret_cast<uint4*>(k_lds + key * KP + piece * 16) = v;
-        }
-        if (vec_v) {
-            for (int pc = tid; pc < NCT * 32 * (KT / 8); pc += 256) {
-                const int c = pc / (KT / 8), piece = pc % (KT / 8);
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (c < CH && kt0 + piece * 8 < T)
-                    v = *reinterpret_cast<const uint4*>(vt + ((size_t)b * C + (size_t)h * CH + c) * T + kt0 + piece * 8);
-                *reinterpret_cast<uint4*>(v_lds + c * VP + piece * 16) = v;
+        {
+            uint4 kv[KIT];
+#pragma unroll
+            for (int i = 0; i < KIT; ++i) {
+                const int pc = tid + 256 * i;
+                const int key = KEXACT ? pc / KPC : min(pc / KPC, KT - 1), piece = pc % KPC;
+                kv[i] = *reinterpret_cast<const uint4*>(kbase + (size_t)min(kt0 + key, T - 1) * row2c + piece * 8);
             }
-        } else {
-            for (int e = tid; e < NCT * 32 * KT; e += 256) {
-                const int c = e / KT, key = e % KT;
-                bf16_raw v = 0;
-                if (c < CH && kt0 + key < T) v = vt[((size_t)b * C + (size_t)h * CH + c) * T + kt0 + key];
-                *reinterpret_cast<bf16_raw*>(v_lds + c * VP + key * 2) = v;
+            if (vec_v) {
+                uint4 vv[VIT];
+#pragma unroll
+                for (int i = 0; i < VIT; ++i) {
+                    const int pc = tid + 256 * i;
+                    const int c = pc / VPC, piece = pc % VPC;
+                    const bool ok = (VEXACT || pc < NCT * 32 * VPC) && c < CH && kt0 + piece * 8 < T;
+                    vv[i] = *reinterpret_cast<const uint4*>(vbase + (size_t)(ok ? c : 0) * T + (ok ? kt0 + piece * 8 : 0));
+                    if (!ok) vv[i] = make_uint4(0u, 0u, 0u, 0u);
+                }
+#pragma unroll
+                for (int i = 0; i < VIT; ++i) {
+                    const int pc = tid + 256 * i;
+                    const int c = pc / VPC, piece = pc % VPC;
+                    if (VEXACT || pc < NCT * 32 * VPC) *reinterpret_cast<uint4*>(v_lds + c * VP + piece * 16) = vv[i];
+                }
+            } else {
+                for (int e = tid; e < NCT * 32 * KT; e += 256) {
+                    const int c = e / KT, key = e % KT;
+                    bf16_raw v = 0;
+                    if (c < CH && kt0 + key < T) v = vbase[(size_t)c * T + kt0 + key];
+                    *reinterpret_cast<bf16_raw*>(v_lds + c * VP + key * 2) = v;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < KIT; ++i) {
+                const int pc = tid + 256 * i;
+                const int key = pc / KPC, piece = pc % KPC;
+                if (KEXACT || pc < KT * KPC)
+                    *reinterpret_cast<uint4*>(k_lds + KL::at(key, piece * 16)) = (kt0 + key < T) ? kv[i] : make_uint4(0u, 0u, 0u, 0u);
             }
         }
         __syncthreads();
@@ -140,32 +184,38 @@ __global__ __launch_bounds__(256) void k_attn_dq(const bf16_raw* __restrict__ qk
             f32x16_t s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
-            const char* kp = k_lds + (32 * u + prow) * KP + 16 * half;
+            const int krow = 32 * u + prow;
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) {
-                const uint4 a = *reinterpret_cast<const uint4*>(kp + 32 * kk);
+                const uint4 a = *reinterpret_cast<const uint4*>(k_lds + KL::at(krow, 16 * half + 32 * kk));
                 s = mma_bf16(a, qf[kk], s);
                 // dP^T[key][q]: A = V[key][ch] read transposed out of the [ch][key] tile, rows in pi order
                 const int r0 = (16 * kk + 8 * (grp >> 1) + qq) * VP + (32 * u + 16 * (grp & 1) + 4 * pswap) * 2;
                 const uint4 av = tr_frag2(v_lds, r0, r0 + 4 * VP);
                 dp = mma_bf16(av, dof[kk], dp);
             }
-            // dS^T = P^T * (dP^T - delta) * scale, masked keys -> 0
+            // dS^T = P^T * (dP^T - delta) * scale; masked keys (partial last tile only) -> P = exp2(-inf) = 0
+            if (kt0 + KT > T) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (kt0 + 32 * u + pi_row(row) >= T) s[r] = -INFINITY;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int key = kt0 + 32 * u + pi_row(row);
-                const float pv = (key < T) ? exp2f(s[r] * scale_log2e - lse_q) : 0.0f;
-                s[r] = pv * (dp[r] - del_q) * scale;
+                const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, nlse_q));
+                s[r] = pv * fmaf(dp[r], scale, ndel_q);
             }
             // dQ^T[c][q] += K^T[c][key] * dS^T[key][q]
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 const uint4 bs = acc_to_frag(s, st);
+                const int rk = 32 * u + 16 * st + 8 * (grp >> 1) + qq;
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) {
-                    const int r0 = (32 * u + 16 * st + 8 * (grp >> 1) + qq) * KP + (32 * ct + 16 * (grp & 1) + 4 * pp) * 2;
-                    const uint4 ak = tr_frag2(k_lds, r0, r0 + 4 * KP);
+                    const int cb = (32 * ct + 16 * (grp & 1) + 4 * pp) * 2;
+                    const uint4 ak = tr_frag2(k_lds, KL::at(rk, cb), KL::at(rk + 4, cb));
                     dq[ct] = mma_bf16(ak, bs, dq[ct]);
                 }
             }
@@ -185,20 +235,26 @@ __global__ __launch_bounds__(256) void k_attn_dq(const bf16_raw* __restrict__ qk
     }
 }
 
-// ------------------------------------------------------------------------------------------------ dK, dV (bf16)
-template <int CH, int QT>
-__global__ __launch_bounds__(256) void k_attn_dkv(const bf16_raw* __restrict__ qk, const bf16_raw* __restrict__ vt,
+// ------------------------------------------------------------------------------------------------ dK / dV (bf16)
+// Key-stationary (128 keys / workgroup, key on the lane), sweeping query tiles.  One kernel per gradient
+// (WHAT = 0: dV = P^T dO, WHAT = 1: dK = dS^T Q): together they hold two 64-register accumulators plus the K and V
+// operand fragments (another 64), which forces one wave per SIMD with every LDS / barrier wait exposed; apart they run
+// two workgroups per CU, for one extra recompute of S.
+template <int CH, int QT, int WHAT>
+__global__ __launch_bounds__(256, CH <= 128 ? 2 : 1) void k_attn_dkv(const bf16_raw* __restrict__ qk, const bf16_raw* __restrict__ vt,
                                                   const bf16_raw* __restrict__ dout, const float* __restrict__ lse,
-                                                  const float* __restrict__ delta, bf16_raw* __restrict__ dqk,
-                                                  bf16_raw* __restrict__ dv, int T, int C, float scale_log2e, float scale,
-                                                  int dqk_rs, int dv_rs) {
-    constexpr int KP = CH * 2 + 16;
+                                                  const float* __restrict__ delta, bf16_raw* __restrict__ dst, int T, int C,
+                                                  float scale_log2e, float scale, int dst_rs, int dst_off) {
+    using QL = RowTile<CH>;
+    constexpr int KP = QL::P;
     constexpr int NKK = CH / 16;
     constexpr int NCT = (CH + 31) / 32;
     constexpr int NU = QT / 32;
-    __shared__ __attribute__((aligned(16))) char q_lds[QT * KP];     // Q  [query][ch]
-    __shared__ __attribute__((aligned(16))) char d_lds[QT * KP];     // dO [query][ch]
-    __shared__ float lse_s[QT], del_s[QT];
+    constexpr bool DK = (WHAT == 1);
+    __shared__ __attribute__((aligned(16))) char q_lds[QT * KP];                 // Q  [query][ch]
+    __shared__ __attribute__((aligned(16))) char d_lds[QT * KP];                 // dO [query][ch]
+    __shared__ __attribute__((aligned(16))) float nlse_s[QT];                    // -lse           (+inf rows: masked)
+    __shared__ __attribute__((aligned(16))) float ndel_s[DK ? QT : 4];           // -delta * scale
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
     const int grp = lane >> 4, li = lane & 15, qq = li >> 2, pp = li & 3;
     const int b = blockIdx.z, h = blockIdx.y, heads = gridDim.y;
@@ -208,7 +264,7 @@ __global__ __launch_bounds__(256) void k_attn_dkv(const bf16_raw* __restrict__ q
     const size_t row2c = (size_t)2 * C;
 
     // K fragments (B operand: lane = key, 8 consecutive channels)
-    uint4 kf[NKK], vf[NKK];
+    uint4 kf[NKK], vf[DK ? NKK : 1];
     {
         const bf16_raw* kp = qk + ((size_t)b * T + kc) * row2c + C + (size_t)h * CH + 8 * half;
 #pragma unroll
@@ -216,7 +272,7 @@ __global__ __launch_bounds__(256) void k_attn_dkv(const bf16_raw* __restrict__ q
     }
     // V fragments (B operand: lane = key, k = channel): V^T is channel-major, so each element is its own
     // 2-byte load -- once per workgroup, outside the query sweep
-    {
+    if constexpr (DK) {
         const bf16_raw* vp = vt + ((size_t)b * C + (size_t)h * CH + 8 * half) * T + kc;
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk) {
@@ -231,29 +287,48 @@ __global__ __launch_bounds__(256) void k_attn_dkv(const bf16_raw* __restrict__ q
         }
     }
 
-    f32x16_t dkacc[NCT], dvacc[NCT];
+    f32x16_t acc[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { dkacc[ct][r] = 0.0f; dvacc[ct][r] = 0.0f; }
+        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
     const int prow = pi_row(col);
+
+    constexpr int QPC = CH / 8;
+    constexpr int QIT = (QT * QPC + 255) / 256;
+    constexpr bool QEXACT = (QIT * 256 == QT * QPC);
+    const bf16_raw* const qbase = qk + (size_t)b * T * row2c + (size_t)h * CH;
+    const bf16_raw* const dbase = dout + (size_t)b * T * C + (size_t)h * CH;
+    const float* const lbase = lse + ((size_t)b * heads + h) * T;
+    const float* const ebase = delta + ((size_t)b * heads + h) * T;
 
     for (int qt0 = 0; qt0 < T; qt0 += QT) {
         __syncthreads();
-        for (int pc = tid; pc < QT * (CH / 8); pc += 256) {
-            const int q = pc / (CH / 8), piece = pc % (CH / 8);
-            uint4 vq = make_uint4(0u, 0u, 0u, 0u), vd = vq;
-            if (qt0 + q < T) {
-                vq = *reinterpret_cast<const uint4*>(qk + ((size_t)b * T + qt0 + q) * row2c + (size_t)h * CH + piece * 8);
-                vd = *reinterpret_cast<const uint4*>(dout + ((size_t)b * T + qt0 + q) * C + (size_t)h * CH + piece * 8);
+        {
+            uint4 vq[QIT], vd[QIT];
+#pragma unroll
+            for (int i = 0; i < QIT; ++i) {
+                const int pc = tid + 256 * i;
+                const int q = QEXACT ? pc / QPC : min(pc / QPC, QT - 1), piece = pc % QPC;
+                const size_t qr = (size_t)min(qt0 + q, T - 1);
+                vq[i] = *reinterpret_cast<const uint4*>(qbase + qr * row2c + piece * 8);
+                vd[i] = *reinterpret_cast<const uint4*>(dbase + qr * C + piece * 8);
             }
-            *reinterpret_cast<uint4*>(q_lds + q * KP + piece * 16) = vq;
-            *reinterpret_cast<uint4*>(d_lds + q * KP + piece * 16) = vd;
-        }
-        if (tid < QT) {
-            const bool ok = qt0 + tid < T;
-            lse_s[tid] = ok ? lse[((size_t)b * heads + h) * T + qt0 + tid] : INFINITY;   // exp2(-inf) = 0 masks the row
-            del_s[tid] = ok ? delta[((size_t)b * heads + h) * T + qt0 + tid] : 0.0f;
+            if (tid < QT) {
+                const bool ok = qt0 + tid < T;
+                nlse_s[tid] = ok ? -lbase[qt0 + tid] : -INFINITY;          // exp2(-inf) = 0 masks the row
+                if constexpr (DK) ndel_s[tid] = ok ? -ebase[qt0 + tid] * scale : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < QIT; ++i) {
+                const int pc = tid + 256 * i;
+                const int q = pc / QPC, piece = pc % QPC;
+                if (QEXACT || pc < QT * QPC) {
+                    const bool ok = qt0 + q < T;
+                    *reinterpret_cast<uint4*>(q_lds + QL::at(q, piece * 16)) = ok ? vq[i] : make_uint4(0u, 0u, 0u, 0u);
+                    *reinterpret_cast<uint4*>(d_lds + QL::at(q, piece * 16)) = ok ? vd[i] : make_uint4(0u, 0u, 0u, 0u);
+                }
+            }
         }
         __syncthreads();
 
@@ -262,52 +337,59 @@ __global__ __launch_bounds__(256) void k_attn_dkv(const bf16_raw* __restrict__ q
             f32x16_t s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
-            const char* qp = q_lds + (32 * u + prow) * KP + 16 * half;
-            const char* dp_ = d_lds + (32 * u + prow) * KP + 16 * half;
+            const int qrow = 32 * u + prow;
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) {
-                const uint4 aq = *reinterpret_cast<const uint4*>(qp + 32 * kk);
-                const uint4 ad = *reinterpret_cast<const uint4*>(dp_ + 32 * kk);
-                s = mma_bf16(aq, kf[kk], s);        // S[q][key]
-                dp = mma_bf16(ad, vf[kk], dp);      // dP[q][key]
+                const uint4 aq = *reinterpret_cast<const uint4*>(q_lds + QL::at(qrow, 16 * half + 32 * kk));
+                s = mma_bf16(aq, kf[kk], s);                 // S[q][key]
+                if constexpr (DK) {
+                    const uint4 ad = *reinterpret_cast<const uint4*>(d_lds + QL::at(qrow, 16 * half + 32 * kk));
+                    dp = mma_bf16(ad, vf[kk], dp);           // dP[q][key]
+                }
             }
+            // accumulator registers 4g..4g+3 hold the 4 consecutive queries 32u + pi(8g + 4 half) + {0..3}
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int q = 32 * u + pi_row(row);
-                const float pv = exp2f(s[r] * scale_log2e - lse_s[q]);
-                dp[r] = pv * (dp[r] - del_s[q]) * scale;     // dS
-                s[r] = pv;                                   // P
+            for (int g = 0; g < 4; ++g) {
+                const int q4 = 32 * u + pi_row(8 * g + 4 * half);
+                const float4 nl = *reinterpret_cast<const float4*>(&nlse_s[q4]);
+                const float nlv[4] = {nl.x, nl.y, nl.z, nl.w};
+                if constexpr (DK) {
+                    const float4 nd = *reinterpret_cast<const float4*>(&ndel_s[q4]);
+                    const float ndv[4] = {nd.x, nd.y, nd.z, nd.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float pv = __builtin_amdgcn_exp2f(fmaf(s[4 * g + j], scale_log2e, nlv[j]));
+                        s[4 * g + j] = pv * fmaf(dp[4 * g + j], scale, ndv[j]);     // dS
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s[4 * g + j] = __builtin_amdgcn_exp2f(fmaf(s[4 * g + j], scale_log2e, nlv[j]));   // P
+                }
             }
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                const uint4 bp = acc_to_frag(s, st);
-                const uint4 bs = acc_to_frag(dp, st);
+                const uint4 bf = acc_to_frag(s, st);
+                const int rq = 32 * u + 16 * st + 8 * (grp >> 1) + qq;
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) {
-                    const int r0 = (32 * u + 16 * st + 8 * (grp >> 1) + qq) * KP + (32 * ct + 16 * (grp & 1) + 4 * pp) * 2;
-                    const uint4 ado = tr_frag2(d_lds, r0, r0 + 4 * KP);     // dO^T[c][q]
-                    const uint4 aq = tr_frag2(q_lds, r0, r0 + 4 * KP);      // Q^T[c][q]
-                    dvacc[ct] = mma_bf16(ado, bp, dvacc[ct]);
-                    dkacc[ct] = mma_bf16(aq, bs, dkacc[ct]);
+                    const int cb = (32 * ct + 16 * (grp & 1) + 4 * pp) * 2;
+                    // dV: dO^T[c][q] * P[q][key];  dK: Q^T[c][q] * dS[q][key]
+                    const uint4 a = tr_frag2(DK ? q_lds : d_lds, QL::at(rq, cb), QL::at(rq + 4, cb));
+                    acc[ct] = mma_bf16(a, bf, acc[ct]);
                 }
             }
         }
     }
     if (kj < T) {
-        bf16_raw* okp = dqk + ((size_t)b * T + kj) * dqk_rs + C + (size_t)h * CH;
-        bf16_raw* ovp = dv + ((size_t)b * T + kj) * dv_rs + (size_t)h * CH;
+        bf16_raw* op = dst + ((size_t)b * T + kj) * dst_rs + dst_off + (size_t)h * CH;
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int c = 32 * ct + 8 * rg + 4 * half;
-                if (c < CH) {
-                    *reinterpret_cast<uint2*>(okp + c) = make_uint2(pack_bf16x2(dkacc[ct][4 * rg + 0], dkacc[ct][4 * rg + 1]),
-                                                                    pack_bf16x2(dkacc[ct][4 * rg + 2], dkacc[ct][4 * rg + 3]));
-                    *reinterpret_cast<uint2*>(ovp + c) = make_uint2(pack_bf16x2(dvacc[ct][4 * rg + 0], dvacc[ct][4 * rg + 1]),
-                                                                    pack_bf16x2(dvacc[ct][4 * rg + 2], dvacc[ct][4 * rg + 3]));
-                }
+                if (c < CH)
+                    *reinterpret_cast<uint2*>(op + c) = make_uint2(pack_bf16x2(acc[ct][4 * rg + 0], acc[ct][4 * rg + 1]),
+                                                                   pack_bf16x2(acc[ct][4 * rg + 2], acc[ct][4 * rg + 3]));
             }
     }
 }
@@ -456,8 +538,10 @@ extern "C" int rho_attention_bwd(const void* qk, const void* vt, const void* o, 
     case chv:                                                                                                                  \
         hipLaunchKernelGGL((k_attn_dq<chv, ktv>), grid, block, 0, st, (const bf16_raw*)qk, (const bf16_raw*)vt,                  \
                            (const bf16_raw*)dout, lse, delta_ws, (bf16_raw*)dqk, (int)t, C, sl2, scale, qrs);                   \
-        hipLaunchKernelGGL((k_attn_dkv<chv, ktv>), grid, block, 0, st, (const bf16_raw*)qk, (const bf16_raw*)vt,                 \
-                           (const bf16_raw*)dout, lse, delta_ws, (bf16_raw*)dqk, (bf16_raw*)dv, (int)t, C, sl2, scale, qrs, vrs); \
+        hipLaunchKernelGGL((k_attn_dkv<chv, ktv, 0>), grid, block, 0, st, (const bf16_raw*)qk, (const bf16_raw*)vt,              \
+                           (const bf16_raw*)dout, lse, delta_ws, (bf16_raw*)dv, (int)t, C, sl2, scale, vrs, 0);                  \
+        hipLaunchKernelGGL((k_attn_dkv<chv, ktv, 1>), grid, block, 0, st, (const bf16_raw*)qk, (const bf16_raw*)vt,              \
+                           (const bf16_raw*)dout, lse, delta_ws, (bf16_raw*)dqk, (int)t, C, sl2, scale, qrs, C);                 \
         break;
         switch (ch) {
             RHO_ATTB(16, 64)
