@@ -46,23 +46,43 @@ __device__ __forceinline__ uint4 acc_to_frag(const f32x16_t& v, int st) {
 }
 
 // ------------------------------------------------------------------------------------------------ delta
+// One 16-byte piece (8 bf16 / 4 f32 channels) of one (b, q) row per lane; the ch / PE lanes of a head are
+// consecutive lanes of one wave (ch / PE is a power of two <= 64), reduced with butterfly shuffles: coalesced
+// 16-byte loads at HBM rate instead of one thread walking a head's channels.
 template <typename T>
 __global__ __launch_bounds__(256) void k_attn_delta(const T* __restrict__ o, const T* __restrict__ dout, float* __restrict__ delta,
                                                     int64_t BT, int heads, int ch, int64_t T_) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over (b*T + q, h)
-    if (i >= BT * heads) return;
-    const int h = (int)(i % heads);
-    const int64_t bq = i / heads;
-    const T* po = o + (bq * heads + h) * ch;
-    const T* pd = dout + (bq * heads + h) * ch;
-    float acc = 0.0f;
-    for (int c = 0; c < ch; ++c) {
-        float a, b;
-        if constexpr (sizeof(T) == 2) { a = bf16_to_f32(po[c]); b = bf16_to_f32(pd[c]); } else { a = po[c]; b = pd[c]; }
-        acc = fmaf(a, b, acc);
+    constexpr int PE = 16 / (int)sizeof(T);
+    const int lph = ch / PE;                       // lanes per head
+    const int64_t npc = BT * heads * lph;          // pieces in total
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t ic = i < npc ? i : npc - 1;      // tail lanes shadow the last piece (uniform shuffles), no store
+    const uint4 a = reinterpret_cast<const uint4*>(o)[ic];
+    const uint4 b = reinterpret_cast<const uint4*>(dout)[ic];
+    float acc;
+    if constexpr (sizeof(T) == 2) {
+        acc = __uint_as_float(a.x << 16) * __uint_as_float(b.x << 16);
+        acc = fmaf(__uint_as_float(a.x & 0xFFFF0000u), __uint_as_float(b.x & 0xFFFF0000u), acc);
+        acc = fmaf(__uint_as_float(a.y << 16), __uint_as_float(b.y << 16), acc);
+        acc = fmaf(__uint_as_float(a.y & 0xFFFF0000u), __uint_as_float(b.y & 0xFFFF0000u), acc);
+        acc = fmaf(__uint_as_float(a.z << 16), __uint_as_float(b.z << 16), acc);
+        acc = fmaf(__uint_as_float(a.z & 0xFFFF0000u), __uint_as_float(b.z & 0xFFFF0000u), acc);
+        acc = fmaf(__uint_as_float(a.w << 16), __uint_as_float(b.w << 16), acc);
+        acc = fmaf(__uint_as_float(a.w & 0xFFFF0000u), __uint_as_float(b.w & 0xFFFF0000u), acc);
+    } else {
+        acc = __uint_as_float(a.x) * __uint_as_float(b.x);
+        acc = fmaf(__uint_as_float(a.y), __uint_as_float(b.y), acc);
+        acc = fmaf(__uint_as_float(a.z), __uint_as_float(b.z), acc);
+        acc = fmaf(__uint_as_float(a.w), __uint_as_float(b.w), acc);
     }
-    const int64_t b_ = bq / T_, q = bq % T_;
-    delta[(b_ * heads + h) * T_ + q] = acc;
+    for (int m = 1; m < lph; m <<= 1) acc += __shfl_xor(acc, m, 64);
+    if (i < npc && (i % lph) == 0) {
+        const int64_t hq = i / lph;                // (b*T + q) * heads + h
+        const int h = (int)(hq % heads);
+        const int64_t bq = hq / heads;
+        const int64_t b_ = bq / T_, q = bq % T_;
+        delta[(b_ * heads + h) * T_ + q] = acc;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ LDS tile layout
@@ -524,7 +544,9 @@ extern "C" int rho_attention_bwd(const void* qk, const void* vt, const void* o, 
     const float scale = (float)(1.0 / sqrt((double)ch));
     const float sl2 = (float)(1.4426950408889634 / sqrt((double)ch));
     hipStream_t st = as_stream(stream);
-    const int64_t nd = batch * t * heads;
+    const int pe = dtype == RHO_BF16 ? 8 : 4;
+    if (ch % pe != 0 || ch / pe > 64 || ((ch / pe) & (ch / pe - 1)) != 0) return RHO_E_SHAPE;
+    const int64_t nd = batch * t * heads * (ch / pe);
     if (dtype == RHO_BF16)
         hipLaunchKernelGGL(k_attn_delta<bf16_raw>, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st, (const bf16_raw*)o,
                            (const bf16_raw*)dout, delta_ws, batch * t, (int)heads, (int)ch, t);

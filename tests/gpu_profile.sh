@@ -1,0 +1,14 @@
+#!/bin/bash
+# rocprofv3 kernel statistics of the default bench command (both legs), then the plain bench line.
+# usage (GPU box): bash tests/gpu_profile.sh <tag>   -> gpurun_out/prof_<tag>/, gpurun_out/bench_<tag>.log
+TAG=${1:-run}
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out
+export TMPDIR=/tmp
+cd /tmp
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --mode both --steps 5 --warmup 2 --train-steps 3 --no-cpu-baseline --no-roofline > $R/gpurun_out/rocprof_$TAG.log 2>&1
+echo "rocprof exit $?"
+cd $R
+timeout -k 10 900 python bench.py --dump-ops gpurun_out/ops_$TAG.txt > gpurun_out/bench_$TAG.log 2>&1
+echo "bench exit $?"
+tail -c 3000 gpurun_out/bench_$TAG.log

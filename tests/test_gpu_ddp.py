@@ -60,7 +60,7 @@ def _worker(rank, world, port, q):
         ddpm.random_timesteps = lambda bs, tt=t: tt
         trainer.step(x0)
     flat = torch.cat([p_.detach().reshape(-1) for p_ in ddpm.backbone.parameters()]).cpu()
-    q.put((rank, flat))
+    q.put((rank, flat.numpy()))      # by value: a torch tensor travels as an fd owned by this (exiting) process
     dist.barrier()
     dist.destroy_process_group()
 
@@ -75,7 +75,7 @@ def test_dp_trainer_two_ranks_match_single_process():
     got = {}
     for _ in range(2):
         r, flat = q.get(timeout=300)
-        got[r] = flat
+        got[r] = torch.from_numpy(flat)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
