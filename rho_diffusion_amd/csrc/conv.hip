@@ -95,7 +95,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
     const int piece = tid & 3;
 
     // ---- tile coordinates
-    const int bt = blockIdx.x;
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Give every XCD a contiguous range of
+    // tiles instead of every 8th one, so that the halo faces shared by neighbouring tiles are re-read from the same L2.
+    int bt = blockIdx.x;
+    {
+        const int nt = gridDim.x, per = nt >> 3;
+        if (per > 0) {
+            const int full = per << 3;                      // tiles covered by the 8 equal ranges; the tail keeps its index
+            if (bt < full) bt = (bt & 7) * per + (bt >> 3);
+        }
+    }
     const int tw_i = bt % p.tiles_w;
     const int th_i = (bt / p.tiles_w) % p.tiles_h;
     const int td_i = bt / (p.tiles_w * p.tiles_h);
@@ -207,18 +216,30 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
         }                                                                                               \
     } while (0)
 
-    // Pipelined variant (3 | NS, i.e. every kernel with more than one tap): a 3-slot LDS weight ring, slot = step % 3.
-    // Step q's tile is fetched at step q-4, handed to LDS at the end of step q-2 (two steps in flight) and read from
-    // step q-1 on, i.e. one barrier AFTER it was written - so the fragment reads of step q+1 can be issued while
-    // step q's MFMAs run, instead of right after the barrier with every wave of the workgroup waiting on them.
+    // Pipelined variant (3 | NS, i.e. every kernel with more than one tap): an R-slot LDS weight ring, slot = step % R.
+    // Step q's tile is fetched at step q-LD into register set q % 3, handed to LDS at the end of step q-D (two steps in
+    // flight) and read from step q-1 on, at least one barrier AFTER it was written - so the fragment reads of step q+1
+    // are issued while step q's MFMAs run, instead of right after a barrier with every wave of the workgroup waiting.
+    // GB = steps per barrier: a write at step q needs a barrier in (q, q+D-1] before its first read and one in
+    // (q+D-R, q] after the slot's last read, i.e. D = GB+1 and R >= 2*GB+1 (R = 9 for GB = 3 keeps the slot static).
     constexpr bool PIPE = (NS % 3 == 0) && (G == 1);
+    // measured on the 8-wave 128-cout variant: GB = 3, R = 9 is 3 % SLOWER than a barrier per tap (131 vs 127 ms per
+    // c3 step) - the per-tap barrier is not what limits this kernel - so GB stays 1.
+    constexpr int GB = 1;
+    constexpr int RS = (GB == 3) ? 9 : 3;          // LDS ring slots
+    constexpr int DS = GB + 1;                     // store distance
+    constexpr int LD = DS + 2;                     // load distance
     if constexpr (PIPE) {
         RHO_LOAD_W(0, 0, 0);
         RHO_LOAD_W(1, 0, 1);
         RHO_LOAD_W(2, 0, 2);
         RHO_STORE_W(0, 0);
         RHO_STORE_W(1, 1);
-        RHO_LOAD_W(0, (3 < NS) ? 0 : min(1, nck - 1), 3 % NS);
+        if constexpr (DS > 2) RHO_STORE_W(2, 2);
+#pragma unroll
+        for (int q = 3; q < LD; ++q) RHO_LOAD_W(q % 3, min(q / NS, nck - 1), q % NS);
+#pragma unroll
+        for (int q = 3; q < DS; ++q) RHO_STORE_W(q % RS, q % 3);
     } else {
         // steps 0 .. PD-1 of chunk 0 in flight (PD <= NS), step 0 landed in LDS slot 0
 #pragma unroll
@@ -323,11 +344,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
             frag_reads(0, 0, 0, xa, xb);
 #pragma unroll
             for (int st = 0; st < NS; ++st) {
-                {   // step st + 4 -> register set (st + 1) % 3 (its previous tile went to LDS at the end of step st - 1);
+                {   // step st + LD -> register set (st + LD) % 3 (its previous tile went to LDS at the end of step st - 1);
                     // unconditional and clamped, so the loads in flight are a static count (counted vmcnt, no drain)
-                    const int nst = (st + 4) % NS;
-                    const int nckk = min(ck + (st + 4) / NS, nck - 1);
-                    RHO_LOAD_W((st + 1) % 3, nckk, nst);
+                    const int nst = (st + LD) % NS;
+                    const int nckk = min(ck + (st + LD) / NS, nck - 1);
+                    RHO_LOAD_W((st + LD) % 3, nckk, nst);
                 }
                 if constexpr (HPF) {
                     if (st == TPF) {
@@ -336,20 +357,20 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                frag_reads(st, st % 3, 1, ya, yb);
+                frag_reads(st, st % RS, 1, ya, yb);
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi) {
                     mma_step<T>(xa[mi], xb[0], acc[mi][0]);
                     mma_step<T>(xa[mi], xb[1], acc[mi][1]);
                 }
-                if (st + 1 < NS) frag_reads(st + 1, (st + 1) % 3, 0, xa, xb);   // next chunk's first step: after its halo is staged
+                if (st + 1 < NS) frag_reads(st + 1, (st + 1) % RS, 0, xa, xb);  // next chunk's first step: after its halo is staged
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi) {
                     mma_step<T>(ya[mi], yb[0], acc[mi][0]);
                     mma_step<T>(ya[mi], yb[1], acc[mi][1]);
                 }
-                RHO_STORE_W((st + 2) % 3, (st + 2) % 3);       // step st + 2 (slot last read in step st - 1)
-                __syncthreads();
+                RHO_STORE_W((st + DS) % RS, (st + DS) % 3);    // step st + DS (slot last read in step st + DS - RS)
+                if (st % GB == GB - 1) __syncthreads();
             }
         } else {
             // ---- all taps out of the resident tile, G taps per barrier step
@@ -593,7 +614,7 @@ extern "C" int rho_conv_nd_fwd(const rho_conv_desc* dp, void* stream) {
 
     const size_t lds_cap = 160 * 1024;
     const int taps = d.kd * d.kh * d.kw;
-    const int WSLOTS = (taps % 3 == 0) ? 3 : 2;                 // LDS weight-ring depth (matches the kernel's PIPE)
+    const int WSLOTS = (taps % 3 == 0) ? 3 : 2;                 // LDS weight-ring depth (matches the kernel's PIPE / RS)
     int np_cap = (int)((lds_cap - (size_t)WSLOTS * BM * PITCH) / PITCH);
     if (np_cap > 28 * 64) np_cap = 28 * 64;
     // prefer the small-halo (2 blocks / CU) configuration when it exists
