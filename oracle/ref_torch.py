@@ -332,6 +332,99 @@ def training_loss(model, x0: Tensor, t: Tensor, noise: Tensor, alpha_bar: Tensor
     return F.mse_loss(pred, noise)
 
 
+# --------------------------------------------------------------------------- GaussianDiffusionPipeline
+def gd_betas(schedule_name: str, num_steps: int):
+    """rho_diffusion/diffusion/gaussian_diffusion.py:45-89 (get_named_beta_schedule / betas_for_alpha_bar), float64 numpy."""
+    import numpy as np
+    if schedule_name == "linear":
+        scale = 1000 / num_steps
+        return np.linspace(scale * 0.0001, scale * 0.02, num_steps, dtype=np.float64)
+    if schedule_name == "cosine":
+        ab = lambda t: math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2
+        return np.array([min(1 - ab((i + 1) / num_steps) / ab(i / num_steps), 0.999) for i in range(num_steps)])
+    raise NotImplementedError(f"unknown beta schedule: {schedule_name}")
+
+
+def gd_tables(betas) -> Dict[str, "object"]:
+    """The float64 coefficient tables of GaussianDiffusionPipeline.__init__ (gaussian_diffusion.py:237-273)."""
+    import numpy as np
+    betas = np.array(betas, dtype=np.float64)
+    alphas = 1.0 - betas
+    ac = np.cumprod(alphas, axis=0)
+    ac_prev = np.append(1.0, ac[:-1])
+    pv = betas * (1.0 - ac_prev) / (1.0 - ac)
+    return {
+        "betas": betas, "alphas_cumprod": ac, "alphas_cumprod_prev": ac_prev, "alphas_cumprod_next": np.append(ac[1:], 0.0),
+        "sqrt_alphas_cumprod": np.sqrt(ac), "sqrt_one_minus_alphas_cumprod": np.sqrt(1.0 - ac),
+        "log_one_minus_alphas_cumprod": np.log(1.0 - ac), "sqrt_recip_alphas_cumprod": np.sqrt(1.0 / ac),
+        "sqrt_recipm1_alphas_cumprod": np.sqrt(1.0 / ac - 1), "posterior_variance": pv,
+        "posterior_log_variance_clipped": np.log(np.append(pv[1], pv[1:])),
+        "posterior_mean_coef1": betas * np.sqrt(ac_prev) / (1.0 - ac),
+        "posterior_mean_coef2": (1.0 - ac_prev) * np.sqrt(alphas) / (1.0 - ac),
+    }
+
+
+def _gd_extract(arr, t: Tensor, shape) -> Tensor:
+    """_extract_into_tensor (gaussian_diffusion.py:91-105): float64 table -> gathered -> float32 -> broadcast."""
+    res = torch.from_numpy(arr)[t].float()
+    while res.dim() < len(shape):
+        res = res[..., None]
+    return res.expand(shape)
+
+
+def gd_q_sample(tab, x_start: Tensor, t: Tensor, noise: Tensor) -> Tensor:
+    """gaussian_diffusion.py:294-312."""
+    return (_gd_extract(tab["sqrt_alphas_cumprod"], t, x_start.shape) * x_start
+            + _gd_extract(tab["sqrt_one_minus_alphas_cumprod"], t, x_start.shape) * noise)
+
+
+def gd_dynamic_threshold(x: Tensor, percentile: float = 0.9) -> Tensor:
+    """process_xstart with clip_denoised (gaussian_diffusion.py:400-415): per-sample quantile of |x| over all other
+    axes, floored at 1, clamp to +-s and divide by s."""
+    s = torch.quantile(x.reshape(x.shape[0], -1).abs(), percentile, dim=-1)
+    s.clamp_(min=1.0)
+    s = s.view(-1, *((1,) * (x.dim() - 1)))
+    return x.clamp(-s, s) / s
+
+
+def gd_ddim_step(tab, x: Tensor, t: Tensor, model_output: Tensor, noise: Tensor, eta: float = 0.0):
+    """ddim_sample for the pipeline's fixed configuration (x0-prediction, fixed-large variance, clip_denoised=True):
+    gaussian_diffusion.py:654-702 on top of p_mean_variance :338-443 and _predict_eps_from_xstart :462-466."""
+    pred_xstart = gd_dynamic_threshold(model_output)
+    eps = (_gd_extract(tab["sqrt_recip_alphas_cumprod"], t, x.shape) * x - pred_xstart) / _gd_extract(
+        tab["sqrt_recipm1_alphas_cumprod"], t, x.shape)
+    alpha_bar = _gd_extract(tab["alphas_cumprod"], t, x.shape)
+    alpha_bar_prev = _gd_extract(tab["alphas_cumprod_prev"], t, x.shape)
+    sigma = eta * torch.sqrt((1 - alpha_bar_prev) / (1 - alpha_bar)) * torch.sqrt(1 - alpha_bar / alpha_bar_prev)
+    mean_pred = pred_xstart * torch.sqrt(alpha_bar_prev) + torch.sqrt(1 - alpha_bar_prev - sigma ** 2) * eps
+    nonzero_mask = (t != 0).float().view(-1, *([1] * (x.dim() - 1)))
+    return mean_pred + nonzero_mask * sigma * noise, pred_xstart
+
+
+def gd_reverse_process(model, tab, x_init: Tensor, noise_tape: Sequence[Tensor], y=None, t_checkpoints=None, eta: float = 0.0):
+    """GaussianDiffusionPipeline.reverse_process (gaussian_diffusion.py:1029-1099).  ``x_init`` replaces the
+    ``randn_like(x_T)`` start (:1039), ``noise_tape[i]`` the ``randn_like(x)`` of loop iteration i (:687).
+    model(x, t[B] long, y) -> x0 prediction."""
+    T = len(tab["betas"])
+    x_t = x_init
+    buf = None
+    if t_checkpoints is not None:
+        ncp = len(t_checkpoints)
+        buf = torch.zeros((x_init.shape[0], ncp) + tuple(x_init.shape[1:]), dtype=x_init.dtype)
+        per = T // ncp
+    else:
+        ncp, per = 0, T
+    t_idx = 0
+    for i, t in enumerate(range(T - 1, -1, -1)):
+        tt = torch.full((x_init.shape[0],), t, dtype=torch.long)
+        out = model(x_t, tt, y)
+        x_t, _ = gd_ddim_step(tab, x_t, tt, out, noise_tape[i], eta)
+        if buf is not None and t % per == 0 and t_idx < ncp:
+            buf[:, t_idx] = x_t
+            t_idx += 1
+    return {"buffer": buf, "denoised": x_t}
+
+
 def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, beta1=0.9, beta2=0.999,
                eps=1e-8, weight_decay=1e-2):
     """torch.optim.AdamW single-tensor update (abstract_diffusion.py:103-119 builds it with

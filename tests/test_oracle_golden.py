@@ -141,6 +141,47 @@ def test_g5_ddpm(T):
     assert rel_l2(buf, torch.from_numpy(g[f"T{T}/buffer"])) < 1e-3
 
 
+GD_TABLES = ("betas", "alphas_cumprod", "alphas_cumprod_prev", "alphas_cumprod_next", "sqrt_alphas_cumprod",
+             "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
+             "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped", "posterior_mean_coef1",
+             "posterior_mean_coef2")
+
+
+@pytest.mark.parametrize("case,T", [("tiny2d", 1000), ("tiny2d", 50), ("tiny3d", 20)])
+def test_g9_gaussian_pipeline(case, T):
+    """GaussianDiffusionPipeline sampling path: tables bit-exact, q_sample, dynamic thresholding,
+    DDIM steps (eta 0 and 0.5; t = 0, mid, T-1) and the replayed reverse_process trajectory."""
+    g = load_golden("g9_gaussian.npz")
+    g4 = load_golden("g4_unet.npz")
+    tag = f"{case}_T{T}"
+    cfg, _, _, _ = case_inputs(case)
+    xshape = UNET_CASES[case][1]
+    tab = R.gd_tables(R.gd_betas("cosine", T))
+    for k in GD_TABLES:
+        assert np.array_equal(tab[k], g[f"{tag}/tab/{k}"]), k          # float64, same numpy expressions: bit-exact
+    x0 = det_uniform(xshape, "gd_x0", -1.0, 1.0)
+    eps = det_normal(xshape, "gd_eps")
+    tq = torch.from_numpy(g[f"{tag}/t"])
+    assert torch.equal(R.gd_q_sample(tab, x0, tq, eps), torch.from_numpy(g[f"{tag}/q_sample"]))
+    scale = torch.tensor([0.3] + [2.5 + i for i in range(xshape[0] - 1)]).view(-1, *([1] * (len(xshape) - 1)))
+    fake = det_normal(xshape, "gd_fake") * scale
+    xt = det_normal(xshape, "gd_xt")
+    for name, tt in (("mid", tq), ("zero", torch.zeros_like(tq)), ("last", torch.full_like(tq, T - 1))):
+        for eta in (0.0, 0.5):
+            sample, px = R.gd_ddim_step(tab, xt, tt, fake, eps, eta)
+            assert torch.equal(px, torch.from_numpy(g[f"{tag}/pmv_{name}/pred_xstart"])), (name, eta)
+            assert torch.equal(sample, torch.from_numpy(g[f"{tag}/ddim_{name}_eta{eta}/sample"])), (name, eta)
+    assert float(px[0].abs().max()) < 1.0 and float(px[1].abs().max()) == 1.0     # floor at 1 / clamp+rescale both exercised
+    if T <= 50:
+        sd = det_state_dict(golden_template(g4, case), case)
+        tape = [det_normal(xshape, f"gdtape{T}_{i}") for i in range(T + 1)]
+        with torch.no_grad():
+            model = lambda x, t, y: R.unet_forward(sd, cfg, x, t)  # noqa: E731
+            res = R.gd_reverse_process(model, tab, tape[0], tape[1:], None, t_checkpoints=[0, 1, 2])
+        assert rel_l2(res["denoised"], torch.from_numpy(g[f"{tag}/denoised"])) < 1e-4
+        assert rel_l2(res["buffer"], torch.from_numpy(g[f"{tag}/buffer"])) < 1e-4
+
+
 def test_g8_adamw():
     g = load_golden("g8_adamw.npz")
     p = det_normal((257,), "adam_p")
