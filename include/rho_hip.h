@@ -217,6 +217,30 @@ int rho_gn_bwd_apply(const void* g, const void* x1, int64_t c1, const void* x2, 
 int rho_gn_apply(const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t n, int64_t s,
                  const float* a, const float* b, int pre_silu, void* y, void* stream);
 
+/* ---- GaussianDiffusionPipeline sampling path -------------------------------------------------
+ * Dynamic thresholding, gaussian_diffusion.py:400-415: out[b] = torch.quantile(|x[b, :]|, q) ("linear"
+ * interpolation, evaluated in float32 exactly as ATen does: rank = float(q) * float(n-1), floor / ceil order
+ * statistics found EXACTLY by a radix select, then lerp).  x: float32 [batch, n] contiguous; workspace: at least
+ * rho_abs_quantile_workspace_bytes(batch) bytes of device memory (contents undefined on entry). */
+int64_t rho_abs_quantile_workspace_bytes(int64_t batch);
+int rho_abs_quantile(const float* x, int64_t batch, int64_t n, double q, void* workspace, float* out, void* stream);
+
+/* q_sample with explicit float32 coefficient tables: x_t = a[t_b] * x0 + b[t_b] * eps  (GaussianDiffusionPipeline.q_sample,
+ * gaussian_diffusion.py:294-312, a = float(sqrt(abar)), b = float(sqrt(1-abar)) as _extract_into_tensor casts them).
+ * x0 / eps / x_t: float32 [batch, per_sample]; t: int64 [batch] on the device. */
+int rho_q_sample_coef(const float* x0, const float* eps, float* x_t, const float* coef_a, const float* coef_b,
+                      const int64_t* t, int64_t batch, int64_t per_sample, void* stream);
+
+/* One DDIM update for an x0-predicting model, gaussian_diffusion.py:654-702 (+ :400-415, :462-466), float32:
+ *   s = max(quantile[b], 1);  x0 = clamp(model_out, -s, s) / s;  eps = (c_recip * x_t - x0) / c_recipm1
+ *   x_prev = x0 * sqrt_abar_prev + coef_eps * eps + sigma_masked * noise
+ * c_recip = sqrt(1/abar_t), c_recipm1 = sqrt(1/abar_t - 1), coef_eps = sqrt(1 - abar_prev - sigma^2),
+ * sigma_masked = (t != 0) * sigma, all float32 scalars prepared by the caller as the reference computes them.
+ * noise may be NULL when sigma_masked == 0 (eta = 0); pred_xstart may be NULL. */
+int rho_ddim_step(const float* x_t, const float* model_out, const float* quantile, const float* noise, float* x_prev,
+                  float* pred_xstart, int64_t batch, int64_t per_sample, float c_recip, float c_recipm1,
+                  float sqrt_abar_prev, float coef_eps, float sigma_masked, void* stream);
+
 /* Channel sums of a channels-last tensor (conv bias gradients; additive-embedding gradients):
  * out_nc[n*nc_stride + c] (+)= sum_pos x[n,pos,c];  out_c[c] (+)= sum_n out_nc[n][c] (optional).
  * partials: scratch sized like rho_gn_partial's. */

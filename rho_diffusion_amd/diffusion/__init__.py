@@ -2,3 +2,4 @@ from . import schedule  # noqa: F401
 from .schedule import LinearSchedule, CosineBetaSchedule, SigmoidSchedule  # noqa: F401
 from .abstract_diffusion import AbstractDiffusionPipeline  # noqa: F401
 from .ddpm import DDPM  # noqa: F401
+from .gaussian_diffusion import GaussianDiffusionPipeline  # noqa: F401

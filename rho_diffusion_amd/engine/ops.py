@@ -57,6 +57,40 @@ def p_sample_step(x: Tensor, eps_hat: Tensor, z: Optional[Tensor], coef_table: T
     return x
 
 
+def q_sample_coef(x0: Tensor, eps: Tensor, t: Tensor, coef_a: Tensor, coef_b: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """x_t = a[t] * x0 + b[t] * eps with explicit float32 tables (GaussianDiffusionPipeline.q_sample)."""
+    x0, eps, coef_a, coef_b = _f32c(x0, "x0"), _f32c(eps, "eps"), _f32c(coef_a, "coef_a"), _f32c(coef_b, "coef_b")
+    if t.dtype != torch.int64 or not t.is_cuda:
+        raise RhoHipError("t must be an int64 GPU tensor")
+    out = torch.empty_like(x0) if out is None else out
+    B = x0.shape[0]
+    check(hip.lib().rho_q_sample_coef(ptr(x0), ptr(eps), ptr(out), ptr(coef_a), ptr(coef_b), ptr(t), B, x0.numel() // B, stream()),
+          "rho_q_sample_coef")
+    return out
+
+
+def abs_quantile(x: Tensor, q: float, out: Optional[Tensor] = None, workspace: Optional[Tensor] = None) -> Tensor:
+    """Per-sample torch.quantile(|x|.flatten(1), q) (float32, linear interpolation), exact radix select on the device."""
+    x = _f32c(x, "x")
+    B = x.shape[0]
+    need = hip.lib().rho_abs_quantile_workspace_bytes(B)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty((need + 3) // 4, dtype=torch.int32, device=x.device)
+    out = torch.empty(B, dtype=torch.float32, device=x.device) if out is None else out
+    check(hip.lib().rho_abs_quantile(ptr(x), B, x.numel() // B, float(q), ptr(workspace), ptr(out), stream()), "rho_abs_quantile")
+    return out
+
+
+def ddim_step(x_t: Tensor, model_out: Tensor, quantile: Tensor, noise: Optional[Tensor], x_prev: Tensor, pred_xstart: Optional[Tensor],
+              c_recip: float, c_recipm1: float, sqrt_abar_prev: float, coef_eps: float, sigma_masked: float) -> Tensor:
+    _f32c(x_t, "x_t"), _f32c(model_out, "model_out"), _f32c(quantile, "quantile"), _f32c(x_prev, "x_prev")
+    B = x_t.shape[0]
+    check(hip.lib().rho_ddim_step(ptr(x_t), ptr(model_out), ptr(quantile), ptr(noise), ptr(x_prev), ptr(pred_xstart), B,
+                                  x_t.numel() // B, c_recip, c_recipm1, sqrt_abar_prev, coef_eps, sigma_masked, stream()),
+          "rho_ddim_step")
+    return x_prev
+
+
 def step_advance(t_dev: Optional[Tensor], offset_dev: Optional[Tensor], delta: int) -> None:
     check(hip.lib().rho_step_advance(ptr(t_dev), ptr(offset_dev), delta, stream()), "rho_step_advance")
 

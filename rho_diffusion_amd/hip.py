@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "librho_hip.so")
 RHO_F32 = 0
 RHO_BF16 = 1
 
-c_void_p, c_int, c_int32, c_int64, c_uint64, c_float = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_uint64, C.c_float
+c_void_p, c_int, c_int32, c_int64, c_uint64, c_float, c_double = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
 
 
 class ConvDesc(C.Structure):
@@ -67,6 +67,11 @@ SIGNATURES = {
     "rho_gn_bwd_apply": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "rho_gn_apply": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "rho_abs_quantile_workspace_bytes": (c_int64, [c_int64]),
+    "rho_abs_quantile": (c_int, [c_void_p, c_int64, c_int64, c_double, c_void_p, c_void_p, c_void_p]),
+    "rho_q_sample_coef": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "rho_ddim_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_float,
+                              c_float, c_float, c_float, c_void_p]),
     "rho_chan_sum": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p]),
     "rho_upsample2x": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
     "rho_pool2x_sum": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
