@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", choices=["sample", "train", "both"], default="both",
+    ap.add_argument("--mode", choices=["sample", "train", "ddim", "both"], default="both",
                     help="sample: denoising steps/s; train: training samples/s; both (default): `value` is the denoising rate, "
                          "the training rate rides along in the same JSON line")
     ap.add_argument("--train-steps", type=int, default=None, help="timed training steps in --mode both (default: --steps)")
@@ -64,6 +64,11 @@ def build_model(args, device):
             if float(p.abs().max()) == 0.0:
                 p.normal_(0.0, 0.02)
     return ddpm.to(device), kw
+
+
+def hip_ws_bytes(batch):
+    from rho_diffusion_amd import hip
+    return int(hip.lib().rho_abs_quantile_workspace_bytes(batch))
 
 
 def cpu_baseline(kw, ddpm, args):
@@ -214,16 +219,45 @@ def main():
         if rank == 0 and not args.no_roofline:
             roofline = roofline_of(next(iter(engine._plans.values())), args)
 
+    if args.mode in ("ddim", "both"):
+        # the GaussianDiffusionPipeline step (x0-prediction UNet + dynamic thresholding + DDIM eta = 0),
+        # same backbone / engine, reported beside the headline as "ddim_sampling"
+        from rho_diffusion_amd.diffusion.gaussian_diffusion import ddim_coefficients, diffusion_tables, get_named_beta_schedule
+        gtab = diffusion_tables(get_named_beta_schedule("cosine", 1000))
+        xd = ddpm.noise(torch.empty(shape, device=device))
+        td = torch.full((1,), 999, dtype=torch.int32, device=device)
+        quant = torch.empty(B, dtype=torch.float32, device=device)
+        qws = torch.empty((hip_ws_bytes(B) + 3) // 4, dtype=torch.int32, device=device)
+        state = {"t": 999}
+
+        def ddim_step():
+            x0_hat = engine.forward(xd, None, None, t_scalar_dev=td)
+            c = ddim_coefficients(gtab, state["t"], 0.0)
+            ops.abs_quantile(x0_hat, 0.9, out=quant, workspace=qws)
+            ops.ddim_step(xd, x0_hat, quant, None, xd, None, *c)
+            ops.step_advance(td, None, 0)
+            state["t"] = max(state["t"] - 1, 1)
+
+        dt = timed(ddim_step, args.steps, args.warmup)
+        assert torch.isfinite(xd).all(), "non-finite DDIM state after the timed steps"
+        results["ddim"] = dict(dt=dt, steps=args.steps)
+        if rank == 0 and not args.no_roofline:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            x0_hat = engine.forward(xd, None, None, t_scalar_dev=td)
+            torch.cuda.synchronize()
+            ev[0].record()
+            ops.abs_quantile(x0_hat, 0.9, out=quant, workspace=qws)
+            ev[1].record()
+            ops.ddim_step(xd, x0_hat, quant, None, xd, None, *ddim_coefficients(gtab, 500, 0.0))
+            ev[2].record()
+            torch.cuda.synchronize()
+            results["ddim"]["quantile_ms"] = ev[0].elapsed_time(ev[1])
+            results["ddim"]["update_ms"] = ev[1].elapsed_time(ev[2])
+
     if args.mode in ("train", "both"):
         # synthetic spherical-harmonics density fields (rho_diffusion/data/synthetic.py:45-124), pool generated once
-        from oracle.ref_torch import spherical_harmonic_field   # input generator only (scipy on the host), not timed
-        import random
-        rng = random.Random(777 + rank)
-        pool = []
-        for _ in range(8):
-            l = rng.randint(0, 5)
-            pool.append(spherical_harmonic_field(l, rng.randint(-l, l), args.grid, args.dims))
-        data = torch.stack([pool[i % len(pool)] for i in range(B)]).to(device).contiguous()
+        from rho_diffusion_amd.data import SphericalHarmonicPool   # host generator (scipy), built once, not timed
+        data = SphericalHarmonicPool(args.grid, args.dims, size=8, seed=777 + rank).batch(B, device)
         from rho_diffusion_amd.trainer import DPTrainer
         trainer = DPTrainer(ddpm, lr=1e-4)
         last = {}
@@ -248,8 +282,8 @@ def main():
             if roofline is None:
                 roofline = roofline_of(tp, args)
 
-    if "sample" in results:
-        r = results["sample"]
+    if "sample" in results or "ddim" in results:
+        r = results["sample"] if "sample" in results else results["ddim"]
         metric, unit, value, steps, dt = "denoising_steps_per_sec", "steps/s", world * r["steps"] / r["dt"], r["steps"], r["dt"]
     else:
         r = results["train"]
@@ -267,6 +301,15 @@ def main():
     }
     if "sample" in results:
         out["config"]["sample_steps_per_sec"] = world * B * results["sample"]["steps"] / results["sample"]["dt"]
+    if "ddim" in results:
+        r = results["ddim"]
+        out["ddim_sampling"] = {"metric": "denoising_steps_per_sec", "value": world * r["steps"] / r["dt"], "unit": "steps/s",
+                                "ms_per_step": 1e3 * r["dt"] / r["steps"],
+                                "step": "UNetv2 x0-prediction + exact per-sample 0.9-quantile of |x0| (radix select) + fused DDIM "
+                                        "update (GaussianDiffusionPipeline.reverse_process, eta = 0, cosine betas)"}
+        for k_ in ("quantile_ms", "update_ms"):
+            if k_ in r:
+                out["ddim_sampling"][k_] = round(r[k_], 4)
     if "train" in results:
         r = results["train"]
         out["training"] = {"metric": "training_samples_per_sec", "value": world * B * r["steps"] / r["dt"], "unit": "samples/s",

@@ -32,7 +32,7 @@ from ..registry import registry
 from ..utils import sample_from_discrete_parameter_space, save_model_checkpoint
 from .abstract_diffusion import AbstractDiffusionPipeline
 
-__all__ = ["GaussianDiffusionPipeline", "get_named_beta_schedule", "betas_for_alpha_bar"]
+__all__ = ["GaussianDiffusionPipeline", "get_named_beta_schedule", "betas_for_alpha_bar", "diffusion_tables", "ddim_coefficients"]
 
 
 def betas_for_alpha_bar(num_diffusion_timesteps: int, alpha_bar, max_beta: float = 0.999) -> np.ndarray:
@@ -55,6 +55,40 @@ def get_named_beta_schedule(schedule_name: str, num_diffusion_timesteps: int) ->
     raise NotImplementedError(f"unknown beta schedule: {schedule_name}")
 
 
+def diffusion_tables(betas: np.ndarray) -> dict:
+    """The float64 coefficient tables of GaussianDiffusionPipeline.__init__ (gaussian_diffusion.py:237-273)."""
+    betas = np.array(betas, dtype=np.float64)
+    assert len(betas.shape) == 1, "betas must be 1-D"
+    assert (betas > 0).all() and (betas <= 1).all()
+    alphas = 1.0 - betas
+    ac = np.cumprod(alphas, axis=0)
+    ac_prev = np.append(1.0, ac[:-1])
+    pv = betas * (1.0 - ac_prev) / (1.0 - ac)
+    return {
+        "betas": betas, "alphas_cumprod": ac, "alphas_cumprod_prev": ac_prev, "alphas_cumprod_next": np.append(ac[1:], 0.0),
+        "sqrt_alphas_cumprod": np.sqrt(ac), "sqrt_one_minus_alphas_cumprod": np.sqrt(1.0 - ac),
+        "log_one_minus_alphas_cumprod": np.log(1.0 - ac), "sqrt_recip_alphas_cumprod": np.sqrt(1.0 / ac),
+        "sqrt_recipm1_alphas_cumprod": np.sqrt(1.0 / ac - 1), "posterior_variance": pv,
+        "posterior_log_variance_clipped": np.log(np.append(pv[1], pv[1:])),
+        "posterior_mean_coef1": betas * np.sqrt(ac_prev) / (1.0 - ac),
+        "posterior_mean_coef2": (1.0 - ac_prev) * np.sqrt(alphas) / (1.0 - ac),
+    }
+
+
+def ddim_coefficients(tables: Mapping[str, np.ndarray], t: int, eta: float = 0.0):
+    """The float32 scalars of ddim_sample (:675-697) for a batch-uniform timestep: tables gathered in float64, cast to
+    float32 (``_extract_into_tensor``), then combined with float32 arithmetic like the reference's tensor expressions.
+    Returns (c_recip, c_recipm1, sqrt_abar_prev, coef_eps, sigma_masked) for rho_ddim_step."""
+    f = np.float32
+    c_recip, c_recipm1 = f(tables["sqrt_recip_alphas_cumprod"][t]), f(tables["sqrt_recipm1_alphas_cumprod"][t])
+    ab, abp = f(tables["alphas_cumprod"][t]), f(tables["alphas_cumprod_prev"][t])
+    one = f(1.0)
+    sigma = f(eta) * np.sqrt((one - abp) / (one - ab), dtype=f) * np.sqrt(one - ab / abp, dtype=f)
+    coef_eps = np.sqrt(one - abp - sigma * sigma, dtype=f)
+    mask = f(1.0 if t != 0 else 0.0)
+    return float(c_recip), float(c_recipm1), float(np.sqrt(abp, dtype=f)), float(coef_eps), float(mask * sigma)
+
+
 class GaussianDiffusionPipeline(AbstractDiffusionPipeline):
     def __init__(self, backbone, backbone_kwargs: dict, schedule, loss_func, timesteps: Union[int, Tensor] = 1000,
                  cond_fn: str = None, cond_fn_kwargs: dict = None, optimizer=None,
@@ -75,24 +109,10 @@ class GaussianDiffusionPipeline(AbstractDiffusionPipeline):
         self.rescale_timesteps = False
 
         # float64 tables (:237-273)
-        betas = np.array(get_named_beta_schedule("cosine", int(timesteps)), dtype=np.float64)
-        self.betas = betas
-        assert len(betas.shape) == 1, "betas must be 1-D"
-        assert (betas > 0).all() and (betas <= 1).all()
-        self.timesteps = int(betas.shape[0])
-        alphas = 1.0 - betas
-        self.alphas_cumprod = np.cumprod(alphas, axis=0)
-        self.alphas_cumprod_prev = np.append(1.0, self.alphas_cumprod[:-1])
-        self.alphas_cumprod_next = np.append(self.alphas_cumprod[1:], 0.0)
-        self.sqrt_alphas_cumprod = np.sqrt(self.alphas_cumprod)
-        self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - self.alphas_cumprod)
-        self.log_one_minus_alphas_cumprod = np.log(1.0 - self.alphas_cumprod)
-        self.sqrt_recip_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod)
-        self.sqrt_recipm1_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod - 1)
-        self.posterior_variance = betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
-        self.posterior_log_variance_clipped = np.log(np.append(self.posterior_variance[1], self.posterior_variance[1:]))
-        self.posterior_mean_coef1 = betas * np.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
-        self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - self.alphas_cumprod)
+        self.tables = diffusion_tables(get_named_beta_schedule("cosine", int(timesteps)))
+        for k_, v_ in self.tables.items():
+            setattr(self, k_, v_)
+        self.timesteps = int(self.betas.shape[0])
         self.dynamic_thresholding_percentile = 0.9
 
         self.noise_seed = int(os.environ.get("RHO_SEED", "777")) + int(os.environ.get("RANK", "0"))
@@ -137,16 +157,7 @@ class GaussianDiffusionPipeline(AbstractDiffusionPipeline):
 
     # ------------------------------------------------------------------ DDIM coefficients of one step
     def ddim_coefficients(self, t: int, eta: float = 0.0):
-        """The float32 scalars of ddim_sample (:675-697) for a batch-uniform timestep: tables gathered in float64, cast
-        to float32 (``_extract_into_tensor``), then combined with float32 arithmetic like the tensor expressions."""
-        f = np.float32
-        c_recip, c_recipm1 = f(self.sqrt_recip_alphas_cumprod[t]), f(self.sqrt_recipm1_alphas_cumprod[t])
-        ab, abp = f(self.alphas_cumprod[t]), f(self.alphas_cumprod_prev[t])
-        one = f(1.0)
-        sigma = f(eta) * np.sqrt((one - abp) / (one - ab), dtype=f) * np.sqrt(one - ab / abp, dtype=f)
-        coef_eps = np.sqrt(one - abp - sigma * sigma, dtype=f)
-        mask = f(1.0 if t != 0 else 0.0)
-        return float(c_recip), float(c_recipm1), float(np.sqrt(abp, dtype=f)), float(coef_eps), float(mask * sigma)
+        return ddim_coefficients(self.tables, t, eta)
 
     # ------------------------------------------------------------------ sampling
     @torch.no_grad()

@@ -45,10 +45,7 @@ def test_ddim_step_and_q_sample_bit_exact_vs_oracle():
     scale = torch.tensor([0.3, 2.5, 3.5, 1.0]).view(-1, 1, 1, 1)
     m = det_normal(xshape, "gk_m") * scale
     noise = det_normal(xshape, "gk_n")
-    from rho_diffusion_amd.diffusion.gaussian_diffusion import GaussianDiffusionPipeline as GP
-    pipe = GP.__new__(GP)                                           # tables only: no backbone needed for the coefficients
-    for k, v in tab.items():
-        setattr(pipe, k, v)
+    from rho_diffusion_amd.diffusion.gaussian_diffusion import ddim_coefficients
     for t in (0, 1, 17, T - 1):
         for eta in (0.0, 0.5):
             tt = torch.full((xshape[0],), t, dtype=torch.long)
@@ -56,7 +53,7 @@ def test_ddim_step_and_q_sample_bit_exact_vs_oracle():
             quant = ops.abs_quantile(m.to(DEV), 0.9)
             out = torch.empty(xshape, device=DEV)
             px = torch.empty(xshape, device=DEV)
-            c = pipe.ddim_coefficients(t, eta)
+            c = ddim_coefficients(tab, t, eta)
             ops.ddim_step(xt.to(DEV), m.to(DEV), quant, noise.to(DEV), out, px, *c)
             assert torch.equal(px.cpu(), ref_x0), (t, eta)
             # (a) bit-exact against the same float32 operation sequence evaluated op by op in numpy
