@@ -45,7 +45,14 @@ struct ConvK {
     int pair_lg;          // -1: none; else log2 of the row-index bit that pairs two 8-wide halo rows 8 (mod 16) positions apart
     int zs_h, zs_w;       // zero-stuffed input (dgrad of a stride-2 conv): virtual extent H/W, source extent Hs/Ws
     int Hs, Ws;
+    int lgTW, lgTH;       // tile extents are powers of two
+    float inv_ihw, inv_iw;  // 1 / (IH*IW), 1 / IW: exact small-integer division through one float multiply
 };
+
+// floor(a / d) for 0 <= a < 2^20 with inv = 1.0f / d: (a + 0.5) * inv is at least 0.5 / d away from an integer, the
+// float error is ~1e-7 * a / d.  (The integer division sequence costs ~20 VALU instructions; the per-tile setup of the
+// narrow layers ran 1100 VALU instructions of this kind against 430 MFMAs.)
+__device__ __forceinline__ int fdiv_small(int a, float inv) { return (int)(((float)a + 0.5f) * inv); }
 
 
 // Column c (0..31) of MFMA tile m (0..7 = wave*2 + j) -> index of the output position inside the 256-position tile.
@@ -127,9 +134,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
             const int hp = (tid >> 2) + RPP * i;
             int pos = -2, smp = 0;
             if (hp < p.NP) {
-                const int id = hp / ihw;
+                const int id = fdiv_small(hp, p.inv_ihw);
                 const int r = hp - id * ihw;
-                const int ih = r / p.IW;
+                const int ih = fdiv_small(r, p.inv_iw);
                 const int iw = r - ih * p.IW;
                 const int gd = gd_base + id;
                 int gh = gh_base + ih, gw = gw_base + iw;
@@ -153,9 +160,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int pp = tile_position(wpos * 2 + j, lane & 31, p.TW, p.pair_lg);
-        const int pw = pp % p.TW;
-        const int ph = (pp / p.TW) % p.TH;
-        const int pd = pp / (p.TW * p.TH);
+        const int pw = pp & (p.TW - 1);
+        const int ph = (pp >> p.lgTW) & (p.TH - 1);
+        const int pd = pp >> (p.lgTW + p.lgTH);
         offd[j] = pd * p.IH * p.IW * PITCH + 16 * half;
 #pragma unroll
         for (int kh = 0; kh < KH; ++kh) {
@@ -432,9 +439,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int pp = tile_position(wpos * 2 + j, lane & 31, p.TW, p.pair_lg);
-        const int pw = pp % p.TW;
-        const int ph = (pp / p.TW) % p.TH;
-        const int pd = pp / (p.TW * p.TH);
+        const int pw = pp & (p.TW - 1);
+        const int ph = (pp >> p.lgTW) & (p.TH - 1);
+        const int pd = pp >> (p.lgTW + p.lgTH);
         const int od = od0 + pd, oh = oh0 + ph, ow = ow0 + pw;
         if (od >= p.Do || oh >= p.Ho || ow >= p.Wo) continue;
         const long long L = (((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
@@ -631,6 +638,11 @@ extern "C" int rho_conv_nd_fwd(const rho_conv_desc* dp, void* stream) {
     k.sh = d.sh; k.sw = d.sw; k.up_h = d.up_h; k.up_w = d.up_w; k.pre_silu = d.pre_silu; k.y2_f32 = d.y2_f32;
     k.TD = t.TD; k.TH = t.TH; k.TW = t.TW; k.ID = t.ID; k.IH = t.IH; k.IW = t.IW; k.NP = t.NP;
     k.tiles_h = cdiv(k.Ho, t.TH); k.tiles_w = cdiv(k.Wo, t.TW);
+    k.lgTW = 0; k.lgTH = 0;
+    while ((1 << k.lgTW) < t.TW) ++k.lgTW;
+    while ((1 << k.lgTH) < t.TH) ++k.lgTH;
+    if ((1 << k.lgTW) != t.TW || (1 << k.lgTH) != t.TH) return RHO_E_SHAPE;      // choose_tile only returns powers of two
+    k.inv_ihw = 1.0f / (float)(t.IH * t.IW); k.inv_iw = 1.0f / (float)t.IW;
     // 8-wide tiles: pair rows (pd*TH + ph) differing in one bit whose halo offset is 8 (mod 16) positions
     k.pair_lg = -1;
     if (t.TW == 8 && d.sw == 1 && d.sh == 1 && !d.up_h && !d.up_w) {

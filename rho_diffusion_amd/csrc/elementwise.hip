@@ -327,17 +327,35 @@ __device__ __forceinline__ bf16_raw cvt_out<bf16_raw>(float v) { return f32_to_b
 template <typename T>
 __global__ __launch_bounds__(256) void k_pack_input(const float* __restrict__ x, T* __restrict__ y, int64_t n, int64_t c,
                                                     int64_t s, int64_t cpad) {
-    // thread per (sample, position): channel reads are coalesced across the wave for each c
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * s; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t b = i / s, p = i % s;
-        T* dst = y + i * cpad;
-        for (int64_t ch = 0; ch < cpad; ++ch) dst[ch] = cvt_out<T>(ch < c ? x[(b * c + ch) * s + p] : 0.0f);
+    // thread per (sample, position, 16-byte piece): consecutive lanes write consecutive 16-byte pieces of the
+    // channels-last rows (one scalar 2-byte store per channel ran at 0.49 TB/s); the reads of channel ch are
+    // coalesced across the lanes that share a piece index
+    constexpr int PE = 16 / (int)sizeof(T);
+    const int64_t ppr = cpad / PE;                      // pieces per row (cpad is a multiple of 32)
+    const int64_t total = n * s * ppr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t piece = i % ppr, pos = i / ppr;
+        const int64_t b = pos / s, p = pos % s;
+        float v[PE];
+#pragma unroll
+        for (int j = 0; j < PE; ++j) {
+            const int64_t ch = piece * PE + j;
+            v[j] = ch < c ? x[(b * c + ch) * s + p] : 0.0f;
+        }
+        uint4 o;
+        if constexpr (sizeof(T) == 2) {
+            o = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+        } else {
+            o = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+        }
+        reinterpret_cast<uint4*>(y)[i] = o;
     }
 }
 
 extern "C" int rho_pack_input(const float* x, void* y, int dtype, int64_t n, int64_t c, int64_t s, int64_t cpad, void* stream) {
     if (!x || !y || n <= 0 || c <= 0 || s <= 0 || cpad < c) return RHO_E_ARG;
-    dim3 grid(grid_for(n * s, 256)), block(256);
+    if (cpad % 8 != 0) return RHO_E_ALIGN;
+    dim3 grid(grid_for(n * s * (cpad / (dtype == RHO_BF16 ? 8 : 4)), 256)), block(256);
     if (dtype == RHO_BF16)
         hipLaunchKernelGGL(k_pack_input<bf16_raw>, grid, block, 0, as_stream(stream), x, (bf16_raw*)y, n, c, s, cpad);
     else if (dtype == RHO_F32)
