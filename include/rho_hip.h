@@ -154,6 +154,10 @@ typedef struct rho_conv_desc {
     int32_t zs_h, zs_w;    /* input is dY of a stride-2 conv, read zero-stuffed: virtual extent out_h/out_w */
     int32_t out_h, out_w;  /* forward-conv input extents (only with zs_*) */
     const void* res2;      /* optional residual for the y2 region (channels-last): in-place grad accumulation */
+    /* --- GroupNorm statistics of the OUTPUT, fused into the epilogue (saves the separate read of rho_gn_partial) */
+    float* stats;          /* optional: per-tile channel sums of the stored (rounded) output, float32
+                              [N][tiles][2][split] with tiles = rho_conv_stats_tiles(desc): row 0 = sum, row 1 = sum of
+                              squares over the tile's positions; combined in fixed order by rho_gn_finalize2 */
 } rho_conv_desc;
 
 /* n-D convolution, zero padding k/2, as an LDS-halo-staged implicit GEMM on MFMA.
@@ -162,6 +166,11 @@ typedef struct rho_conv_desc {
  * :323,:331 with the residual of :342; stem :535; head :679-683) with the GroupNorm affine +
  * FiLM + SiLU (:212-216, :285-289) applied while the halo tile is staged. */
 int rho_conv_nd_fwd(const rho_conv_desc* desc, void* stream);
+
+/* Number of output tiles per sample the launch of `desc` uses (the middle extent of desc->stats), or 0 when fused
+ * statistics are not available for this geometry (channel-major outputs, tiles that straddle samples: 1-D / 2-D
+ * kernels, 1x1x1 with positions-per-sample not a multiple of 256); callers then fall back to rho_gn_partial. */
+int64_t rho_conv_stats_tiles(const rho_conv_desc* desc);
 
 /* ------------------------------------------------------------------ attention */
 
@@ -209,6 +218,14 @@ int rho_gn_bwd_finalize(const float* partials, int64_t n, int64_t c, int64_t s, 
 int rho_gn_bwd_apply(const void* g, const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t n,
                      int64_t s, const float* a, const float* b, int pre_silu, const float* cA, const float* cP,
                      const float* cQ, void* dx1, void* dx2, int acc1, int acc2, void* stream);
+
+/* rho_gn_finalize over one or two sources (the virtual concat), each with its own partial-sum format:
+ *   fmt 0: rho_gn_partial's layout  [n][nblk][c/8][16]  (8 sums, 8 sums of squares per channel octet)
+ *   fmt 1: a convolution's fused epilogue statistics  [n][nblk][2][c]  (rho_conv_desc.stats, nblk = tiles)
+ * Source 2 is optional (p2 = NULL).  Channels of source 1 come first, c = c1 + c2, groups = 32. */
+int rho_gn_finalize2(const float* p1, int fmt1, int64_t nblk1, int64_t c1, const float* p2, int fmt2, int64_t nblk2,
+                     int64_t c2, int64_t n, int64_t s, const float* gamma, const float* beta, const float* scale,
+                     const float* shift, int64_t film_stride, float* stats, float* a, float* b, void* stream);
 
 /* Materialised prologue  y[n,pos,:] = act(a[n,:] * concat(x1,x2)[n,pos,:] + b[n,:])  (channels-last, dtype of x),
  * bit-identical to what the convolution loaders compute on the fly from the same a / b (GroupNorm32 + FiLM + SiLU,

@@ -45,6 +45,8 @@ struct ConvK {
     int pair_lg;          // -1: none; else log2 of the row-index bit that pairs two 8-wide halo rows 8 (mod 16) positions apart
     int zs_h, zs_w;       // zero-stuffed input (dgrad of a stride-2 conv): virtual extent H/W, source extent Hs/Ws
     int Hs, Ws;
+    float* stats;         // fused GroupNorm statistics of the output: [N][tps][2][split] (see rho_conv_desc.stats)
+    int tps;              // tiles per sample
     int lgTW, lgTH;       // tile extents are powers of two
     float inv_ihw, inv_iw;  // 1 / (IH*IW), 1 / IW: exact small-integer division through one float multiply
 };
@@ -445,7 +447,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
         // also wrote 1.36x the algorithmic bytes.)
         constexpr int ROWB = BM * 4 + 16;                 // odd number of 16-byte slots: conflict-free column writes
         constexpr int PPR = BM / PE;                      // 16-byte output pieces per row
+        static_assert(NTHR % PPR == 0, "a thread keeps one channel piece across its rows (statistics accumulators)");
         char* const stg = smem;
+        float ssum[PE], ssq[PE];                          // GroupNorm partial sums of this thread's channel piece
+#pragma unroll
+        for (int e = 0; e < PE; ++e) ssum[e] = ssq[e] = 0.0f;
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
             __syncthreads();                              // tap loop / previous pass done with the LDS bytes reused here
@@ -498,8 +504,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
                         v[4] += __uint_as_float(r.z << 16); v[5] += __uint_as_float(r.z & 0xFFFF0000u);
                         v[6] += __uint_as_float(r.w << 16); v[7] += __uint_as_float(r.w & 0xFFFF0000u);
                     }
-                    *reinterpret_cast<uint4*>(p.y + eo * 2) =
-                        make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+                    const uint4 o = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+                    *reinterpret_cast<uint4*>(p.y + eo * 2) = o;
+                    if (p.stats != nullptr) {             // statistics of the values as stored (what a reader would see)
+                        v[0] = __uint_as_float(o.x << 16); v[1] = __uint_as_float(o.x & 0xFFFF0000u);
+                        v[2] = __uint_as_float(o.y << 16); v[3] = __uint_as_float(o.y & 0xFFFF0000u);
+                        v[4] = __uint_as_float(o.z << 16); v[5] = __uint_as_float(o.z & 0xFFFF0000u);
+                        v[6] = __uint_as_float(o.w << 16); v[7] = __uint_as_float(o.w & 0xFFFF0000u);
+                    }
                 } else {
                     if (p.res != nullptr) {
                         const float4 r = *reinterpret_cast<const float4*>(p.res + eo * 4);
@@ -507,6 +519,33 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
                     }
                     *reinterpret_cast<float4*>(p.y + eo * 4) = make_float4(v[0], v[1], v[2], v[3]);
                 }
+                if (p.stats != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < PE; ++e) {
+                        ssum[e] += v[e];
+                        ssq[e] = fmaf(v[e], v[e], ssq[e]);
+                    }
+                }
+            }
+        }
+        if (p.stats != nullptr) {
+            // threads tid = piece (mod PPR) hold partials of the same channels: combine through LDS in thread order
+            // (fixed order => reproducible), one (channel, statistic) per finishing thread
+            __syncthreads();
+            float* red = reinterpret_cast<float*>(stg);                     // [NTHR][2 * PE]
+#pragma unroll
+            for (int e = 0; e < PE; ++e) {
+                red[tid * (2 * PE) + e] = ssum[e];
+                red[tid * (2 * PE) + PE + e] = ssq[e];
+            }
+            __syncthreads();
+            const int ns = n + bt / p.tps, ts = bt % p.tps;
+            for (int item = tid; item < PPR * 2 * PE; item += NTHR) {
+                const int piece = item / (2 * PE), e2 = item % (2 * PE);
+                float accv = 0.0f;
+                for (int q = 0; q < NTHR / PPR; ++q) accv += red[(q * PPR + piece) * (2 * PE) + e2];
+                const int stat = e2 / PE, ch = co0 + piece * PE + (e2 % PE);
+                p.stats[(((size_t)ns * p.tps + ts) * 2 + stat) * p.split + ch] = accv;
             }
         }
         return;
@@ -635,7 +674,7 @@ int launch_taps(const rho_conv_desc& d, const ConvK& k, int BM, int np, dim3 gri
 
 }  // namespace
 
-extern "C" int rho_conv_nd_fwd(const rho_conv_desc* dp, void* stream) {
+static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles) {
     if (!dp) return RHO_E_ARG;
     const rho_conv_desc& d = *dp;
     if (!d.x1 || !d.w || !d.bias) return RHO_E_ARG;
@@ -733,10 +772,30 @@ extern "C" int rho_conv_nd_fwd(const rho_conv_desc* dp, void* stream) {
     const long long tiles = (long long)cdiv(k.Do, t.TD) * k.tiles_h * k.tiles_w;
     if (tiles > 0x7FFFFFFFLL || d.coutp / BM > 65535 || gridz > 65535) return RHO_E_SHAPE;
     dim3 grid((unsigned)tiles, (unsigned)(d.coutp / BM), (unsigned)gridz);
+    // fused output statistics: only where a tile belongs to one sample and the whole output is channels-last
+    int64_t tps = 0;
+    if (d.split == d.cout && d.split > 0) {
+        if (d.kd == 3) tps = tiles;
+        else if (taps == 1 && k.S_out % 256 == 0 && t.TW == 256) tps = k.S_out / 256;
+    }
+    if (stats_tiles) { *stats_tiles = tps; return 0; }
+    k.stats = nullptr; k.tps = 1;
+    if (d.stats) {
+        if (tps <= 0) return RHO_E_ARG;
+        k.stats = d.stats; k.tps = (int)tps;
+    }
     size_t lds = (size_t)t.NP * PITCH + (size_t)WSLOTS * BM * PITCH;
+    if (d.stats) { const size_t lr = (size_t)(BM == 128 ? 512 : 256) * 16 * sizeof(float); if (lds < lr) lds = lr; }
     const size_t lds_epi = (size_t)128 * (BM * 4 + 16);       // epilogue transpose staging (fp32 rows, 128 positions per pass)
     if (d.split > 0 && lds < lds_epi) lds = lds_epi;
     hipStream_t st = as_stream(stream);
     if (d.dtype == RHO_BF16) return launch_taps<bf16_raw>(d, k, BM, t.NP, grid, lds, st);
     return launch_taps<float>(d, k, BM, t.NP, grid, lds, st);
+}
+
+extern "C" int rho_conv_nd_fwd(const rho_conv_desc* dp, void* stream) { return conv_impl(dp, stream, nullptr); }
+
+extern "C" int64_t rho_conv_stats_tiles(const rho_conv_desc* dp) {
+    int64_t t = 0;
+    return conv_impl(dp, nullptr, &t) == 0 ? t : 0;
 }

@@ -283,6 +283,7 @@ class _Plan:
         self.ops: List[Callable[[int], int]] = []
         self.info: List[dict] = []     # per launch: kind, algorithmic flops / bytes (for bench roofline)
         self.keep: List[object] = []   # descriptors / tensors referenced by raw pointers
+        self.tstats: Dict[int, Tuple[Tensor, int]] = {}   # conv output data_ptr -> (fused statistics buffer, tiles per sample)
         self.nodes: List[dict] = []
         self.cond_src = None
         L = hip.lib()
@@ -341,11 +342,27 @@ class _Plan:
                 scale = self.film.data_ptr() + 4 * off
                 shift = self.film.data_ptr() + 4 * (off + Cc)
                 stride = self.film.shape[1]
-            a1 = (ptr(x1), c1, ptr(x2), c2, dtc, N, S, ptr(part))
-            a2 = (ptr(part), N, Cc, S, nblk, ptr(norm.weight), ptr(norm.bias), scale, shift, stride, ptr(st), ptr(a), ptr(b))
-            self.ops.append(lambda s, a=a1: L.rho_gn_partial(*a, s))
-            self.info.append(dict(kind="gn_partial", flops=3.0 * N * S * Cc, bytes=float(esz) * N * S * Cc))
-            self.ops.append(lambda s, a=a2: L.rho_gn_finalize(*a, s))
+            # per-source partial sums: the producing convolution's fused epilogue statistics when it has them
+            # (fmt 1, no extra read of the activation), else one rho_gn_partial pass over that source (fmt 0)
+            srcs = []
+            for xi, ci in ((x1, c1), (x2, c2)):
+                if xi is None:
+                    continue
+                ts = self.tstats.get(xi.data_ptr())
+                if ts is not None:
+                    srcs.append((ptr(ts[0]), 1, ts[1], ci))
+                else:
+                    nb_i = ops.gn_nblk(S)
+                    part_i = part if len(srcs) == 0 and x2 is None else buf(N * nb_i * (ci // 8) * 16, dtype=torch.float32)
+                    a1 = (ptr(xi), ci, None, 0, dtc, N, S, ptr(part_i))
+                    self.ops.append(lambda s, a=a1: L.rho_gn_partial(*a, s))
+                    self.info.append(dict(kind="gn_partial", flops=3.0 * N * S * ci, bytes=float(esz) * N * S * ci))
+                    srcs.append((ptr(part_i), 0, nb_i, ci))
+            s1 = srcs[0]
+            s2 = srcs[1] if len(srcs) > 1 else (None, 0, 0, 0)
+            a2 = (s1[0], s1[1], s1[2], s1[3], s2[0], s2[1], s2[2], s2[3], N, S, ptr(norm.weight), ptr(norm.bias), scale, shift,
+                  stride, ptr(st), ptr(a), ptr(b))
+            self.ops.append(lambda s, a=a2: L.rho_gn_finalize2(*a, s))
             self.info.append(dict(kind="gn_finalize", flops=0.0, bytes=4.0 * N * Cc * 4))
             return dict(x1=x1, x2=x2, norm=norm, film_off=off, a=a, b=b, st=st, part=part, N=N, S=S, C=Cc, nblk=nblk)
 
@@ -362,6 +379,13 @@ class _Plan:
             if res_add_off is not None:
                 d.res_add = self.film.data_ptr() + 4 * res_add_off
                 d.res_add_stride = self.film.shape[1]
+            if y is not None and split_ == cout:
+                # GroupNorm statistics of the output ride along in the epilogue where the geometry allows it
+                tiles = int(L.rho_conv_stats_tiles(C.byref(d)))
+                if tiles > 0:
+                    sbuf = buf(N * tiles * 2 * cout, dtype=torch.float32)
+                    d.stats = sbuf.data_ptr()
+                    self.tstats[y.data_ptr()] = (sbuf, tiles)
             self.keep.append(d)
             self.ops.append(lambda s, d=d: L.rho_conv_nd_fwd(C.byref(d), s))
             npos_out = N * Do * Ho * Wo

@@ -31,7 +31,7 @@ class ConvDesc(C.Structure):
         ("kd", c_int32), ("kh", c_int32), ("kw", c_int32), ("sh", c_int32), ("sw", c_int32),
         ("up_h", c_int32), ("up_w", c_int32), ("pre_silu", c_int32), ("res_add_stride", c_int32),
         ("y2_cl", c_int32), ("zs_h", c_int32), ("zs_w", c_int32), ("out_h", c_int32), ("out_w", c_int32),
-        ("res2", c_void_p),
+        ("res2", c_void_p), ("stats", c_void_p),
     ]
 
 
@@ -54,6 +54,9 @@ SIGNATURES = {
     "rho_gn_finalize": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                 c_void_p, c_void_p, c_void_p, c_void_p]),
     "rho_conv_nd_fwd": (c_int, [C.POINTER(ConvDesc), c_void_p]),
+    "rho_conv_stats_tiles": (c_int64, [C.POINTER(ConvDesc)]),
+    "rho_gn_finalize2": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rho_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     # ---- backward
     "rho_conv_nd_wgrad": (c_int, [C.POINTER(ConvDesc), c_void_p, c_int64, c_void_p, c_void_p]),

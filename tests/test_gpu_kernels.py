@@ -309,3 +309,52 @@ def test_attention_online_softmax_rescale(ops):
         qk = torch.cat([qq, kk], 1).permute(0, 2, 1).contiguous().to(DEV).to(dtype)
         out = ops.attention(qk, vv.contiguous().to(DEV).to(dtype), heads)
         assert rel_l2(out.float().cpu().permute(0, 2, 1), ref) < tol(dtype, f32=1e-5, bf16=1e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("kind", ["3d", "3d_ragged", "1x1"])
+def test_conv_fused_groupnorm_statistics(ops, dtype, kind):
+    """rho_conv_desc.stats + rho_gn_finalize2 (fused epilogue statistics) against rho_gn_partial + rho_gn_finalize on the
+    stored output: same (a, b) up to fp32 summation order, for a single source and for a concat with a plain source."""
+    import ctypes as C
+    from rho_diffusion_amd import hip
+    L = hip.lib()
+    N, cin, cout = 2, 32, 64
+    spatial = {"3d": (4, 8, 8), "3d_ragged": (5, 6, 7), "1x1": (4, 8, 8)}[kind]
+    k = 1 if kind == "1x1" else 3
+    x = rnd(det_normal((N, cin, *spatial), kind + "sx"), dtype)
+    w = rnd(det_normal((cout, cin, k, k, k), kind + "sw") / math.sqrt(cin * k ** 3), dtype)
+    b = det_normal((cout,), kind + "sb") * 0.1
+    wp = ops.prep_conv_weight(w.to(DEV), dtype)
+    x_cl = to_cl(x, dtype)
+    S = spatial[0] * spatial[1] * spatial[2]
+    y = torch.empty(N, *spatial, cout, dtype=x_cl.dtype, device=DEV)
+    b_dev = b.to(DEV)                      # the descriptor holds raw pointers: keep every operand alive
+    d = ops.make_conv_desc(x_cl, None, wp, b_dev, kernel=(k, k, k), cout=cout, split=cout, y=y, y2=None)
+    tiles = int(L.rho_conv_stats_tiles(C.byref(d)))
+    assert tiles > 0
+    sbuf = torch.full((N * tiles * 2 * cout,), float("nan"), dtype=torch.float32, device=DEV)
+    d.stats = sbuf.data_ptr()
+    ops.conv_launch(d)
+    assert torch.isfinite(sbuf).all()
+    got = sbuf.view(N, tiles, 2, cout).double().sum(1).cpu()
+    yf = y.float().reshape(N, S, cout).double().cpu()
+    assert torch.allclose(got[:, 0], yf.sum(1), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(got[:, 1], (yf * yf).sum(1), rtol=1e-5, atol=1e-4)
+    # finalize: fused statistics vs the separate pass, also as the first half of a concat
+    extra = to_cl(rnd(det_normal((N, 32, *spatial), kind + "sx2"), dtype), dtype)
+    for x2, c2 in ((None, 0), (extra, 32)):
+        Cc = cout + c2
+        gamma = (1 + 0.2 * det_normal((Cc,), "sg")).to(DEV)
+        beta = (0.1 * det_normal((Cc,), "sbt")).to(DEV)
+        a_ref, b_ref, _ = ops.gn_coeffs(y, x2, gamma, beta)
+        a2 = torch.empty(N, Cc, device=DEV)
+        b2 = torch.empty(N, Cc, device=DEV)
+        p2, nb2 = None, 0
+        if x2 is not None:
+            nb2 = ops.gn_nblk(S)
+            p2 = torch.empty(N * nb2 * (c2 // 8) * 16, device=DEV)
+            hip.check(L.rho_gn_partial(ops.ptr(x2), c2, None, 0, hip.dtype_code(dtype), N, S, ops.ptr(p2), ops.stream()), "gn_partial")
+        hip.check(L.rho_gn_finalize2(ops.ptr(sbuf), 1, tiles, cout, ops.ptr(p2), 0, nb2, c2, N, S, ops.ptr(gamma), ops.ptr(beta),
+                                     None, None, 0, None, ops.ptr(a2), ops.ptr(b2), ops.stream()), "gn_finalize2")
+        assert rel_l2(a2.cpu(), a_ref.cpu()) < 1e-5 and rel_l2(b2.cpu(), b_ref.cpu()) < 1e-4
