@@ -189,8 +189,10 @@ int rho_attention_fwd(const void* qk, const void* vt, void* out, float* lse, int
  * conv (inputs + prologue, which is recomputed in the loader); dy is its output gradient, channels-last with
  * row width dy_width (>= cout, padding channels zero); dw is an fp32 buffer [taps][coutp][c1+c2] that the
  * call accumulates into with fp32 atomics (zero it first).  up_h/up_w unsupported: pass the materialised
- * upsampled input (rho_upsample2x). */
-int rho_conv_nd_wgrad(const rho_conv_desc* desc, const void* dy, int64_t dy_width, float* dw, void* stream);
+ * upsampled input (rho_upsample2x).  dbias (optional, float32 [coutp], zeroed by the caller) additionally receives the
+ * bias gradient = per-channel sums of dy over all positions (the dY tiles pass through the kernel anyway; this replaces
+ * a separate rho_chan_sum read of dy). */
+int rho_conv_nd_wgrad(const rho_conv_desc* desc, const void* dy, int64_t dy_width, float* dw, float* dbias, void* stream);
 
 /* dw buffer -> parameter-gradient layout [cout][cin][taps] float32 (undoing the qkv row gather). */
 int rho_wgrad_finalize(const float* dw, float* grad, int64_t cout, int64_t cin, int64_t taps, int64_t coutp,

@@ -30,6 +30,7 @@ struct WgradK {
     const float* pre_b;
     const char* dy;
     float* dw;
+    float* dbias;       // optional [coutp]: channel sums of dY (bias gradient), accumulated by the cin-chunk-0 workgroups
     int c1, c2, cin;
     int dyw;            // row width (elements) of dY
     int coutp;          // rows of the dw buffer
@@ -170,6 +171,13 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     // clamped address and are zeroed later, so all of them are in flight together and visible to the counted
     // vmcnt) are issued before the MFMA phase of tile t and consumed after it.
     uint4 xv[MAXP], dv[8];
+    // bias gradient = channel sums of dY: the dY tile passes through this thread's registers anyway (8 rows x one
+    // 16-byte channel piece per tile); only the workgroups of input-channel chunk 0 add them up (uniform branch)
+    constexpr int DPE = 16 / (int)sizeof(T);
+    const bool do_bias = (p.dbias != nullptr) && (blockIdx.z == 0);
+    float bsum[DPE];
+#pragma unroll
+    for (int e = 0; e < DPE; ++e) bsum[e] = 0.0f;
     int xpos[MAXP];          // global input position of each halo slot (-1 = zero padding) of the tile in flight
     unsigned dok = 0;        // validity bits of the 8 dY rows of the tile in flight
     int n_cur = 0;
@@ -241,6 +249,17 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
             const int row = (tid >> 3) + 32 * i;
             const uint4 u = ((dok >> i) & 1u) ? dv[i] : make_uint4(0u, 0u, 0u, 0u);
             *reinterpret_cast<uint4*>(dyt + row * DYP + ((dpiece * 16) ^ dy_swz(row))) = u;
+            if (do_bias) {
+                if constexpr (IS_BF16) {
+                    bsum[0] += __uint_as_float(u.x << 16); bsum[1] += __uint_as_float(u.x & 0xFFFF0000u);
+                    bsum[2] += __uint_as_float(u.y << 16); bsum[3] += __uint_as_float(u.y & 0xFFFF0000u);
+                    bsum[4] += __uint_as_float(u.z << 16); bsum[5] += __uint_as_float(u.z & 0xFFFF0000u);
+                    bsum[6] += __uint_as_float(u.w << 16); bsum[7] += __uint_as_float(u.w & 0xFFFF0000u);
+                } else {
+                    bsum[0] += __uint_as_float(u.x); bsum[1] += __uint_as_float(u.y);
+                    bsum[2] += __uint_as_float(u.z); bsum[3] += __uint_as_float(u.w);
+                }
+            }
         }
     };
     using I0 = std::integral_constant<int, 0>;
@@ -315,6 +334,22 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
         }
     }
 
+    // ---- bias gradient: threads tid = dpiece (mod 8) hold sums of the same channels -> LDS -> one atomic per channel
+    if (do_bias) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);               // [256][DPE]
+#pragma unroll
+        for (int e = 0; e < DPE; ++e) red[tid * DPE + e] = bsum[e];
+        __syncthreads();
+        if (tid < 8 * DPE) {
+            const int piece = tid / DPE, e = tid % DPE;
+            float accv = 0.0f;
+            for (int q = 0; q < 32; ++q) accv += red[(q * 8 + piece) * DPE + e];
+            const int co = co0 + piece * DPE + e;
+            if (co < p.dyw && co < p.coutp) atomicAdd(p.dbias + co, accv);
+        }
+    }
+
     // ---- flush: lane holds ci = c + (lane&31), rows co0 + 32*mi + (r&3) + 8*(r>>2) + 4*half
     const int ci = c + (lane & 31);
     const bool ci_ok = IS_BF16 ? true : ((lane & 31) < 16);
@@ -376,7 +411,7 @@ inline int ilog2(int v) {
 // (channels-last, row width dy_width >= cout, extra channels must be zero); dw is an fp32 buffer
 // [taps][coutp][c1+c2] that this call ACCUMULATES into (zero it first).  up_h/up_w are not supported:
 // materialise the upsampled input (rho_upsample2x) and pass it as x1.
-extern "C" int rho_conv_nd_wgrad(const rho_conv_desc* dp, const void* dy, int64_t dy_width, float* dw, void* stream) {
+extern "C" int rho_conv_nd_wgrad(const rho_conv_desc* dp, const void* dy, int64_t dy_width, float* dw, float* dbias, void* stream) {
     if (!dp || !dy || !dw) return RHO_E_ARG;
     const rho_conv_desc& d = *dp;
     if (!d.x1) return RHO_E_ARG;
@@ -420,7 +455,7 @@ extern "C" int rho_conv_nd_wgrad(const rho_conv_desc* dp, const void* dy, int64_
     if (!t.ok) return RHO_E_SHAPE;
 
     k.x1 = (const char*)d.x1; k.x2 = (const char*)d.x2; k.pre_a = d.pre_a; k.pre_b = d.pre_b;
-    k.dy = (const char*)dy; k.dw = dw;
+    k.dy = (const char*)dy; k.dw = dw; k.dbias = dbias;
     k.c1 = d.c1; k.c2 = c2; k.cin = cin; k.dyw = (int)dy_width; k.coutp = d.coutp;
     k.sh = d.sh; k.sw = d.sw; k.pre_silu = d.pre_silu;
     k.TD = t.TD; k.TH = t.TH; k.TW = t.TW; k.ID = t.ID; k.IH = t.IH; k.IW = t.IW; k.NP = t.NP;

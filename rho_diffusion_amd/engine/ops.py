@@ -292,9 +292,10 @@ def prep_conv_weight_dgrad(w: Tensor, dtype: torch.dtype, col_src: Optional[Tens
     return out
 
 
-def conv_wgrad(desc: ConvDesc, dy: Tensor, dw: Tensor) -> None:
-    """Accumulate the weight gradient of the forward conv `desc` into the fp32 buffer dw [taps, coutp, cin]."""
-    check(hip.lib().rho_conv_nd_wgrad(C.byref(desc), ptr(dy), dy.shape[-1], ptr(dw), stream()), "rho_conv_nd_wgrad")
+def conv_wgrad(desc: ConvDesc, dy: Tensor, dw: Tensor, dbias: Optional[Tensor] = None) -> None:
+    """Accumulate the weight gradient of the forward conv `desc` into the fp32 buffer dw [taps, coutp, cin] (and, when given,
+    the channel sums of dy = the bias gradient into dbias [coutp])."""
+    check(hip.lib().rho_conv_nd_wgrad(C.byref(desc), ptr(dy), dy.shape[-1], ptr(dw), ptr(dbias), stream()), "rho_conv_nd_wgrad")
 
 
 def wgrad_finalize(dw: Tensor, grad: Tensor, row_src: Optional[Tensor] = None, accumulate: bool = False) -> None:

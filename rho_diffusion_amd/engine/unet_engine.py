@@ -521,11 +521,7 @@ class _Plan:
             nblk = ops.gn_nblk(S)
             part = pool.get((N * nblk * (dyw // 8) * 16,), torch.float32)
             rs = ptr(cw.row_src)
-            # bias gradient: channel sums of dY, then (row-permuted, truncated) accumulate into bias.grad
-            a = (ptr(dY), dtc, N, S, dyw, ptr(part), ptr(nc_tmp), 0, 0, ptr(c_tmp), 0)
-            emit(lambda s, a=a: L.rho_chan_sum(*a, s), "chan_sum", nbytes=float(esz) * N * S * dyw)
-            emit(lambda s, cw=cw, rs=rs, w_=dyw: L.rho_wgrad_finalize(ptr(c_tmp), pgrad(cw.bias_param), cw.cout, 1, 1, w_, 1, rs, 1, s),
-                 "bias_grad")
+            # bias gradient = channel sums of dY: accumulated by the weight-gradient kernel itself (below)
             if node["res_add_off"] is not None:        # additive timestep embedding (unet_v2.py:291)
                 dst = self.dfilm.data_ptr() + 4 * node["res_add_off"]
                 a = (ptr(dY), dtc, N, S, dyw, ptr(part), dst, film_stride, 0, None, 0)
@@ -559,12 +555,16 @@ class _Plan:
             self.keep.append(d)
             nw = cw.taps * cw.coutp * cw.cinp
             dwv = dwbuf[:nw]
-            emit(lambda s, t=dwv: (t.zero_(), 0)[1], "memset", nbytes=4.0 * nw)
-            emit(lambda s, d=d, dy=ptr(dY), w_=dyw: L.rho_conv_nd_wgrad(C.byref(d), dy, w_, ptr(dwbuf), s), "wgrad",
+            cbv = c_tmp[:max(dyw, cw.coutp)]
+            emit(lambda s, t=dwv, t2=cbv: (t.zero_(), t2.zero_(), 0)[2], "memset", nbytes=4.0 * nw)
+            emit(lambda s, d=d, dy=ptr(dY), w_=dyw: L.rho_conv_nd_wgrad(C.byref(d), dy, w_, ptr(dwbuf), ptr(c_tmp), s), "wgrad",
                  flops=2.0 * N * S * cw.cout * cw.cin * cw.taps, nbytes=float(esz) * (x1.numel() + dY.numel()),
                  cin=cw.cin, cout=cw.cout, taps=cw.taps, positions=N * S)
             emit(lambda s, cw=cw, rs=rs: L.rho_wgrad_finalize(ptr(dwbuf), pgrad(cw.weight), cw.cout, cw.cin, cw.taps, cw.coutp,
                                                               cw.cinp, rs, 1, s), "wgrad_finalize", nbytes=8.0 * nw)
+            # (row-permuted, truncated) accumulate of the channel sums into bias.grad
+            emit(lambda s, cw=cw, rs=rs, w_=dyw: L.rho_wgrad_finalize(ptr(c_tmp), pgrad(cw.bias_param), cw.cout, 1, 1, w_, 1, rs, 1, s),
+                 "bias_grad")
             if tmp_up is not None:
                 pool.put(tmp_up)
             if xact is not None:

@@ -110,10 +110,14 @@ def test_conv_dgrad_and_wgrad(ops, dtype, case):
     dfw = ops.make_conv_desc(xin1, xin2, wf, zbw, kernel=kernel, cout=cout, split=cout,
                              y=dycl, y2=None, stride_hw=stride_hw)
     dwbuf = torch.zeros(wf.shape[0], wf.shape[1], wf.shape[2], dtype=torch.float32, device=DEV)
-    ops.conv_wgrad(dfw, dycl, dwbuf)
+    dbias = torch.zeros(wf.shape[1], dtype=torch.float32, device=DEV)
+    ops.conv_wgrad(dfw, dycl, dwbuf, dbias)
     grad = torch.full(tuple(w.shape), 7.0, device=DEV)
     ops.wgrad_finalize(dwbuf, grad)
     assert rel_l2(grad, w.grad) < tolb(dtype), f"wgrad {name}"
+    # bias gradient accumulated by the same kernel = channel sums of dY (as stored in the engine dtype)
+    ref_db = dycl.float().reshape(-1, dycl.shape[-1]).sum(0)[:cout]
+    assert rel_l2(dbias[:cout], ref_db) < 1e-5 and float(dbias[cout:].abs().max() if dbias.numel() > cout else 0.0) == 0.0, f"dbias {name}"
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
