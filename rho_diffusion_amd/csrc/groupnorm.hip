@@ -10,7 +10,10 @@
 #include "common.h"
 
 extern "C" int rho_gn_nblk(int64_t s) {
-    int64_t nb = (s + 2047) / 2048;
+    // position blocks per sample of the partial-sum passes.  256 positions per block: with wide channel counts a block
+    // covers only 256 / (C/8) positions per iteration, and at the deep levels (S = 4096, C = 512..1024) 2048-position
+    // blocks meant 64 workgroups on 256 CUs running 1024 serial iterations each (0.65 TB/s).
+    int64_t nb = (s + 255) / 256;
     if (nb < 1) nb = 1;
     if (nb > 64) nb = 64;
     return (int)nb;
