@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--dims", type=int, default=3)
     ap.add_argument("--mc", type=int, default=64)
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--no-graph", action="store_true", help="launch the sampling step eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -213,9 +214,22 @@ def main():
             ops.p_sample_step(x_t, pred, z, tables["coef"], t_dev)
             ops.step_advance(t_dev, off_dev, (n_elem + 3) // 4)
 
-        dt = timed(sample_step, args.steps, args.warmup)
+        step_fn, graphed = sample_step, False
+        if not args.no_graph:
+            # the step's state (t, Philox offset) lives on the device, so one captured HIP graph serves every step
+            # (DDPM.reverse_process does the same); launch-bound configurations (2-D 64^2) gain 3-4x, c3 nothing
+            try:
+                sample_step()                                   # builds the engine plan outside the capture
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_):
+                    sample_step()
+                step_fn, graphed = g_.replay, True
+            except Exception as exc:  # noqa: BLE001
+                torch.cuda.synchronize()
+                print(f"[bench] HIP graph capture failed ({type(exc).__name__}: {exc}); eager launches", file=sys.stderr)
+        dt = timed(step_fn, args.steps, args.warmup)
         assert torch.isfinite(x_t).all(), "non-finite state after the timed steps"
-        results["sample"] = dict(dt=dt, steps=args.steps)
+        results["sample"] = dict(dt=dt, steps=args.steps, graphed=graphed)
         if rank == 0 and not args.no_roofline:
             roofline = roofline_of(next(iter(engine._plans.values())), args)
 
@@ -300,6 +314,7 @@ def main():
                                   f"all-reduce over RCCL, overlapped with backward)"},
     }
     if "sample" in results:
+        out["config"]["hip_graph"] = bool(results["sample"].get("graphed"))
         out["config"]["sample_steps_per_sec"] = world * B * results["sample"]["steps"] / results["sample"]["dt"]
     if "ddim" in results:
         r = results["ddim"]

@@ -53,6 +53,11 @@ class DDPM(AbstractDiffusionPipeline):
         self._nan_flag = None
         self.nan_check_every = 50
         self._steps_seen = 0
+        # reverse_process: capture one denoising step (Philox draw, UNet forward, update, device-side step advance) in a
+        # HIP graph and replay it; the step index and RNG offset live on the device, so one graph serves every t.  Pays
+        # where the step is launch-bound (2-D 64^2: ~190 launches of a few microseconds each); bit-identical to the
+        # eager loop.  Falls back to the eager loop if capture is not possible (e.g. label lookups that synchronise).
+        self.hip_graph_sampling = os.environ.get("RHO_HIP_GRAPH", "1") != "0"
 
     # ------------------------------------------------------------------ noise
     def noise(self, data: Tensor) -> Tensor:
@@ -114,6 +119,12 @@ class DDPM(AbstractDiffusionPipeline):
         engine = self.backbone.engine() if hasattr(self.backbone, "engine") else None
         t_dev = torch.full((1,), denoise_steps - 1, dtype=torch.int32, device=dev)
         t_idx = 0
+        if (self.hip_graph_sampling and engine is not None and denoise_steps > 2 and "noise" not in self.__dict__
+                and type(self).noise is DDPM.noise):
+            done = self._reverse_process_graph(x_t, cc, engine, tables, t_dev, denoise_steps, buf, steps_per_ckpt, num_checkpoints)
+            if done:
+                return {"buffer": buf, "denoised": x_t}
+            t_dev.fill_(denoise_steps - 1)
         for t in range(denoise_steps - 1, -1, -1):
             z = self.noise(x_t) if t > 1 else None          # drawn before the backbone call (:196-199)
             if engine is not None:
@@ -127,6 +138,53 @@ class DDPM(AbstractDiffusionPipeline):
                 t_idx += 1
             ops.step_advance(t_dev, None, 0)
         return {"buffer": buf, "denoised": x_t}
+
+    def _reverse_process_graph(self, x_t, cc, engine, tables, t_dev, denoise_steps, buf, steps_per_ckpt, num_checkpoints) -> bool:
+        """The loop of reverse_process with steps t = T-2 .. 0 replayed from one captured HIP graph (step T-1 runs eagerly:
+        it builds the engine plan and its buffers).  Same arithmetic and the same Philox stream as the eager loop: z is
+        drawn at the offset the eager loop would use (the draws of t <= 1 are ignored by the update kernel either way).
+        Returns False (nothing modified but the RNG offset bookkeeping) if the capture fails."""
+        dev = x_t.device
+        n_elem = x_t.numel()
+        delta = (n_elem + 3) // 4
+        z = torch.empty_like(x_t)
+        off_dev = torch.full((1,), self._noise_offset, dtype=torch.int64, device=dev)
+        x_save = x_t.clone()
+
+        def step():
+            ops.philox_normal(z, self.noise_seed, 0, offset_dev=off_dev)
+            pred = engine.forward(x_t, None, cc, t_scalar_dev=t_dev)
+            ops.p_sample_step(x_t, pred, z, tables["coef"], t_dev)
+            ops.step_advance(t_dev, off_dev, delta)
+
+        t_idx = 0
+
+        def checkpoint(t):
+            nonlocal t_idx
+            if buf is not None and t % steps_per_ckpt == 0 and t_idx < num_checkpoints:
+                buf[:, t_idx].copy_(x_t)
+                t_idx += 1
+
+        try:
+            step()                                      # t = T-1, eager
+            checkpoint(denoise_steps - 1)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+        except Exception as exc:  # noqa: BLE001  (capture is an optimisation; any failure -> eager loop)
+            torch.cuda.synchronize()
+            x_t.copy_(x_save)
+            if buf is not None:
+                buf.zero_()
+            self.hip_graph_sampling = False
+            import warnings
+            warnings.warn(f"HIP graph capture of the sampling step failed ({type(exc).__name__}: {exc}); using the eager loop")
+            return False
+        for t in range(denoise_steps - 2, -1, -1):
+            graph.replay()
+            checkpoint(t)
+        self._noise_offset += delta * max(denoise_steps - 2, 0)      # eager-loop bookkeeping: one draw per t > 1
+        return True
 
     # ------------------------------------------------------------------ training
     def _check_nan(self) -> None:

@@ -177,3 +177,27 @@ def test_product_path_has_no_cpu_fallback():
     model = UNet(**dict(kw))            # parameters on the CPU
     with pytest.raises(RhoHipError):
         model(torch.zeros(xshape), torch.zeros(xshape[0], dtype=torch.long))
+
+
+def test_reverse_process_hip_graph_matches_eager_loop():
+    """DDPM.reverse_process with the step replayed from a captured HIP graph (device-resident step index and Philox
+    offset) is bit-identical to the eager loop, checkpoints included, and leaves the RNG bookkeeping in the same state."""
+    from torch import nn
+    from rho_diffusion_amd.diffusion import DDPM, LinearSchedule
+    from rho_diffusion_amd.models import UNet
+    g4 = load_golden("g4_unet.npz")
+    case = "tiny2d"
+    kw, xshape, _ = UNET_CASES[case]
+    outs = {}
+    for mode in (True, False):
+        ddpm = DDPM(UNet, dict(kw, compute_dtype="bf16"), LinearSchedule(50, 1e-3, 0.02), nn.MSELoss, timesteps=50)
+        ddpm.backbone.load_state_dict(det_state_dict(golden_template(g4, case), case))
+        ddpm = ddpm.to(DEV)
+        ddpm.hip_graph_sampling = mode
+        res = ddpm.reverse_process(torch.zeros(xshape, device=DEV), None, t_checkpoints=[0, 1, 2])
+        assert ddpm.hip_graph_sampling == mode          # the capture did not fall back
+        outs[mode] = (res["denoised"].clone(), res["buffer"].clone(), ddpm._noise_offset)
+    assert torch.equal(outs[True][0], outs[False][0])
+    assert torch.equal(outs[True][1], outs[False][1])
+    assert outs[True][2] == outs[False][2]
+    assert torch.isfinite(outs[True][0]).all()
