@@ -183,6 +183,11 @@ int64_t rho_conv_stats_tiles(const rho_conv_desc* desc);
 int rho_attention_fwd(const void* qk, const void* vt, void* out, float* lse, int dtype, int64_t batch, int64_t t,
                       int64_t heads, int64_t ch, void* stream);
 
+/* ExponentialMovingAverage.update, rho_diffusion/ema.py:41-60: shadow -= one_minus_frac * (shadow - param),
+ * float32, element-wise over n values (a whole flat parameter arena or one tensor); one_minus_frac = 1 - decay *
+ * (1 - exp(-step / 2000)) is computed by the caller as the reference does. */
+int rho_ema_update(float* shadow, const float* param, int64_t n, float one_minus_frac, void* stream);
+
 /* ================================================================== backward (training) */
 
 /* Weight gradient of rho_conv_nd_fwd (autograd of conv_nd, layers.py:77-88): desc describes the FORWARD

@@ -440,6 +440,13 @@ def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float,
 
 
 # --------------------------------------------------------------------------- inputs
+def ema_update(shadow: Tensor, param: Tensor, step_id: int, decay: float = 0.9999) -> float:
+    """ExponentialMovingAverage.update for one tensor, in place (rho_diffusion/ema.py:41-60); returns the fraction."""
+    frac = decay * (1 - math.exp(-step_id / 2000))
+    shadow.sub_((1.0 - frac) * (shadow - param))
+    return frac
+
+
 def spherical_harmonic_field(l: int, m: int, grid: int, dims: int = 3):
     """Density field of rho_diffusion/data/synthetic.py:45-124 on linspace(-2, 2, G)^3:
     |Y_l^{|m|}(theta, phi) * r| min-max normalised; 2-D = central z slice (the reference

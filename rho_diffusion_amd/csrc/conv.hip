@@ -18,6 +18,8 @@
 //   * Weights ([tap][cout][cin], prepared once) stream through a 2-deep LDS ring, one tap ahead.
 //
 // Replaces conv_nd at every call site of rho_diffusion/models/unet_v2.py (see include/rho_hip.h).
+#include <type_traits>
+
 #include "conv_common.h"
 
 struct ConvK {
@@ -238,6 +240,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
     constexpr int RS = (GB == 3) ? 9 : 3;          // LDS ring slots
     constexpr int DS = GB + 1;                     // store distance
     constexpr int LD = DS + 2;                     // load distance
+    if constexpr (NT != 1) {
     if constexpr (PIPE) {
         RHO_LOAD_W(0, 0, 0);
         RHO_LOAD_W(1, 0, 1);
@@ -432,6 +435,92 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
             }
     }
 
+    } else {
+        // ---- 1x1x1: a GEMM over channel chunks.  There is no halo and one tap per chunk, so the generic path (stage a
+        // chunk, barrier, 8 MFMAs, barrier) exposed one global-load latency per chunk (0.88 ms for the 512 -> 1536 qkv
+        // projection, 0.2 TFLOP).  Here chunk c + DX is fetched into a register ring while chunk c runs, activations and
+        // weights are double-buffered in LDS, and one barrier per chunk orders both the hand-over and the slot reuse.
+        constexpr int XS = (256 + RPP - 1) / RPP;          // activation rows per thread (the tile is 256 linear positions)
+        constexpr int DX = 4;                              // chunks in flight
+        constexpr int HSLOT = 256 * PITCH;
+        char* const wb2 = smem + 2 * HSLOT;                // [2][BM rows]
+        uint4 xq[DX][XS], wx0[DX], wx1[DX];
+#pragma unroll
+        for (int i = 0; i < DX; ++i) wx0[i] = wx1[i] = make_uint4(0u, 0u, 0u, 0u);
+        auto issue = [&](auto SET, int ckk) {
+            constexpr int S_ = decltype(SET)::value;
+            const int cc = min(ckk, nck - 1);              // clamped: static number of loads in flight (counted vmcnt)
+            const int c = cc * CK;
+            const char* src;
+            int cs, csrc;
+            if (c < p.c1) { src = p.x1; cs = p.c1; csrc = c; } else { src = p.x2; cs = p.c2; csrc = c - p.c1; }
+#pragma unroll
+            for (int i = 0; i < XS; ++i) {
+                const int ps = spos[i] > 0 ? spos[i] : 0;
+                xq[S_][i] = *reinterpret_cast<const uint4*>(src + ((size_t)ps * cs + csrc) * sizeof(T) + piece * 16);
+            }
+            const char* ws = w_src0 + (size_t)cc * 64;
+            if (w_active) wx0[S_] = *reinterpret_cast<const uint4*>(ws);
+            if constexpr (WROWS == 2) wx1[S_] = *reinterpret_cast<const uint4*>(ws + RPP * wrow_bytes);
+        };
+        auto land = [&](auto SET, int ck) {                // registers -> LDS slot ck & 1 (prologue applied)
+            constexpr int S_ = decltype(SET)::value;
+            const int c = ck * CK;
+            char* const hs = smem + (ck & 1) * HSLOT;
+#pragma unroll
+            for (int i = 0; i < XS; ++i) {
+                if (spos[i] != -2) {
+                    uint4 u = spos[i] >= 0 ? xq[S_][i] : make_uint4(0u, 0u, 0u, 0u);
+                    if (p.pre_a != nullptr && spos[i] >= 0) {
+                        const int smp = (KD == 3) ? n : ssmp[(KD == 3) ? 0 : i];
+                        const size_t co = (size_t)smp * p.cin + c + piece * PE;
+                        u = apply_pre<T>(u, p.pre_a + co, p.pre_b + co, p.pre_silu);
+                    }
+                    const int hp = (tid >> 2) + RPP * i;
+                    *reinterpret_cast<uint4*>(hs + hp * PITCH + piece * 16) = u;
+                }
+            }
+            char* const wd = wb2 + (ck & 1) * BM * PITCH + w_dst0;
+            if (w_active) *reinterpret_cast<uint4*>(wd) = wx0[S_];
+            if constexpr (WROWS == 2) *reinterpret_cast<uint4*>(wd + RPP * PITCH) = wx1[S_];
+        };
+        auto compute = [&](int ck) {
+            const char* const hs = smem + (ck & 1) * HSLOT;
+            const char* const wcur = wb2 + (ck & 1) * BM * PITCH + a_off;
+            const char* b0p = hs + (offd[0] + offh[0][0] + offw[0][0]);
+            const char* b1p = hs + (offd[1] + offh[1][0] + offw[1][0]);
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+                const uint4 b0 = *reinterpret_cast<const uint4*>(b0p + 32 * s_);
+                const uint4 b1 = *reinterpret_cast<const uint4*>(b1p + 32 * s_);
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) {
+                    const uint4 a = *reinterpret_cast<const uint4*>(wcur + mi * 32 * PITCH + 32 * s_);
+                    mma_step<T>(a, b0, acc[mi][0]);
+                    mma_step<T>(a, b1, acc[mi][1]);
+                }
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>;
+        issue(I0{}, 0); issue(I1{}, 1); issue(I2{}, 2); issue(I3{}, 3);
+#define RHO_ONE_STEP(K_, ISET)                                                                      \
+        if (ck0 + K_ < nck) {                                                                       \
+            land(ISET{}, ck0 + K_);                                                                 \
+            __syncthreads();                                                                        \
+            issue(ISET{}, ck0 + K_ + DX);                                                           \
+            compute(ck0 + K_);                                                                      \
+        }
+        for (int ck0 = 0; ck0 < nck; ck0 += DX) {
+            RHO_ONE_STEP(0, I0)
+            RHO_ONE_STEP(1, I1)
+            RHO_ONE_STEP(2, I2)
+            RHO_ONE_STEP(3, I3)
+        }
+#undef RHO_ONE_STEP
+    }
 #undef RHO_LOAD_W
 #undef RHO_STORE_W
 #undef RHO_HALO_LOAD
@@ -785,6 +874,7 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
         k.stats = d.stats; k.tps = (int)tps;
     }
     size_t lds = (size_t)t.NP * PITCH + (size_t)WSLOTS * BM * PITCH;
+    if (taps == 1) lds = (size_t)2 * 256 * PITCH + (size_t)2 * BM * PITCH;      // 1x1x1: double-buffered activations + weights
     if (d.stats) { const size_t lr = (size_t)(BM == 128 ? 512 : 256) * 16 * sizeof(float); if (lds < lr) lds = lr; }
     const size_t lds_epi = (size_t)128 * (BM * 4 + 16);       // epilogue transpose staging (fp32 rows, 128 positions per pass)
     if (d.split > 0 && lds < lds_epi) lds = lds_epi;

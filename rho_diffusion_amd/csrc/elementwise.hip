@@ -556,6 +556,47 @@ extern "C" int rho_linear_bwd(const float* dout, int64_t dout_stride, const floa
     return 0;
 }
 
+// ExponentialMovingAverage.update (rho_diffusion/ema.py:41-60): shadow -= (1 - frac) * (shadow - param), float32, in the
+// reference's operation order (sub, mul, sub; no contraction) so a parameter-by-parameter comparison is bit-exact.
+__global__ __launch_bounds__(256) void k_ema_update(float* __restrict__ shadow, const float* __restrict__ param, int64_t n, float omf) {
+#pragma clang fp contract(off)
+    const int64_t n4 = n >> 2;
+    const bool vec = ((((uintptr_t)shadow | (uintptr_t)param) & 15) == 0);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        float4* s4 = reinterpret_cast<float4*>(shadow);
+        const float4* p4 = reinterpret_cast<const float4*>(param);
+        for (int64_t i = tid; i < n4; i += stride) {
+            float4 a = s4[i];
+            const float4 b = p4[i];
+            float d;
+            d = a.x - b.x; d = omf * d; a.x = a.x - d;
+            d = a.y - b.y; d = omf * d; a.y = a.y - d;
+            d = a.z - b.z; d = omf * d; a.z = a.z - d;
+            d = a.w - b.w; d = omf * d; a.w = a.w - d;
+            s4[i] = a;
+        }
+        for (int64_t i = (n4 << 2) + tid; i < n; i += stride) {
+            float d = shadow[i] - param[i];
+            d = omf * d;
+            shadow[i] = shadow[i] - d;
+        }
+    } else {
+        for (int64_t i = tid; i < n; i += stride) {
+            float d = shadow[i] - param[i];
+            d = omf * d;
+            shadow[i] = shadow[i] - d;
+        }
+    }
+}
+
+extern "C" int rho_ema_update(float* shadow, const float* param, int64_t n, float one_minus_frac, void* stream) {
+    if (!shadow || !param || n <= 0) return RHO_E_ARG;
+    hipLaunchKernelGGL(k_ema_update, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, as_stream(stream), shadow, param, n, one_minus_frac);
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
 // dst += src (channels-last activations / gradients), 16-byte pieces
 template <typename T>
 __global__ __launch_bounds__(256) void k_add_inplace(T* __restrict__ dst, const T* __restrict__ src, int64_t n) {

@@ -156,3 +156,21 @@ def test_hip_adamw_and_training_reduces_loss():
                 assert rel_l2(p, rp) < 1e-6
         losses.append(loss.item())
     assert losses[-1] < losses[0], losses
+
+
+def test_ema_update_bit_exact_vs_reference_golden():
+    """rho_diffusion_amd.ema.ExponentialMovingAverage (rho_ema_update) vs shadow weights recorded from the reference's class."""
+    from rho_diffusion_amd.ema import ExponentialMovingAverage
+    g = load_golden("g10_ema.npz")
+    net = nn.Sequential(nn.Linear(7, 5), nn.Linear(5, 3))
+    net.load_state_dict(det_state_dict(net.state_dict(), "ema0"))
+    net = net.to(DEV)
+    ema = ExponentialMovingAverage(net, decay=0.9999)
+    for step in range(1, 4):
+        net.load_state_dict({k: v.to(DEV) for k, v in det_state_dict(net.state_dict(), f"ema{step}").items()})
+        if step == 3:
+            ema.step_id = 4999
+        ema.update()
+        assert ema.current_ema_frac == float(g[f"frac{step}"])
+        for k, v in ema.ema_model.state_dict().items():
+            assert torch.equal(v.cpu(), torch.from_numpy(g[f"s{step}/{k}"])), (step, k)

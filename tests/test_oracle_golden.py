@@ -190,3 +190,20 @@ def test_g8_adamw():
     for step in range(1, 4):
         p, m, v = R.adamw_step(p, det_normal((257,), f"adam_g{step}"), m, v, step, lr=1e-4)
         assert rel_l2(p, torch.from_numpy(g[f"p{step}"])) < 1e-6
+
+
+def test_g10_ema():
+    """ExponentialMovingAverage.update (SURVEY 8f #4) against the reference's own class: fractions and shadow weights."""
+    from torch import nn
+    g = load_golden("g10_ema.npz")
+    net = nn.Sequential(nn.Linear(7, 5), nn.Linear(5, 3))
+    shadow = {k: v.clone() for k, v in det_state_dict(net.state_dict(), "ema0").items()}
+    step_id = 0
+    for step in range(1, 4):
+        cur = det_state_dict(net.state_dict(), f"ema{step}")
+        step_id = 5000 if step == 3 else step_id + 1
+        for k in shadow:
+            frac = R.ema_update(shadow[k], cur[k], step_id)
+        assert frac == float(g[f"frac{step}"])
+        for k in shadow:
+            assert torch.equal(shadow[k], torch.from_numpy(g[f"s{step}/{k}"])), (step, k)
