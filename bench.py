@@ -282,7 +282,8 @@ def main():
         tsteps = args.train_steps or args.steps
         dt = timed(train_step, tsteps, max(1, args.warmup))
         assert torch.isfinite(last["loss"]).all(), "non-finite training loss"
-        results["train"] = dict(dt=dt, steps=tsteps, loss=float(last["loss"]))
+        results["train"] = dict(dt=dt, steps=tsteps, loss=float(last["loss"].detach()),
+                                peak_mem_gb=round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1))
         if rank == 0 and not args.no_roofline:
             tp = engine._last_train_plan
             bprof = tp.profile(repeats=1, backward=True)
@@ -329,6 +330,7 @@ def main():
         r = results["train"]
         out["training"] = {"metric": "training_samples_per_sec", "value": world * B * r["steps"] / r["dt"], "unit": "samples/s",
                            "steps": r["steps"], "ms_per_step": 1e3 * r["dt"] / r["steps"], "loss": r["loss"],
+                           "peak_mem_gb": r.get("peak_mem_gb"),
                            "step": "q_sample + UNetv2 fwd + MSE + bwd + " + ("RCCL grad all-reduce + " if world > 1 else "") + "fused AdamW"}
 
     if roofline is not None:

@@ -276,6 +276,8 @@ class _Plan:
         from ..models.unet_v2 import AttentionBlock, Downsample, ResBlock, Upsample
         self.eng = eng
         self.train = train
+        import os as _os
+        self.materialize_act = _os.environ.get("RHO_TRAIN_MATERIALIZE", "1") != "0"   # memory-for-time trade of training plans
         m = eng.model
         dt = eng.dtype
         dtc = hip.dtype_code(dt)
@@ -373,9 +375,23 @@ class _Plan:
             N, Do, Ho, Wo = ops.conv_out_shape(x1.shape, cw.kernel, stride_hw, up_hw)
             y = buf(N, Do, Ho, Wo, split_) if split_ > 0 else None
             y2 = buf(N, cout - split_, Do * Ho * Wo, dtype=y2_dtype or dt) if split_ < cout else None
-            d = ops.make_conv_desc(x1, x2, cw.w, cw.b, kernel=cw.kernel, cout=cout, split=split_, y=y, y2=y2,
-                                   stride_hw=stride_hw, up_hw=up_hw, pre_a=pre["a"] if pre else None,
-                                   pre_b=pre["b"] if pre else None, pre_silu=pre_silu, res=res, res_add=None)
+            xact = None
+            cx1, cx2, cpre = x1, x2, pre
+            if self.train and pre is not None and up_hw == (0, 0) and self.materialize_act:
+                # training: the activated input act(a*x+b) is needed twice (this conv, its weight gradient) and the conv
+                # loader would recompute it 2.3x (halo) per cout tile: materialise it once (one HBM-rate pass, kept for
+                # backward: +1 activation-sized buffer per normalised conv, 38 GB at c3) and feed both from it
+                c1_ = x1.shape[-1]
+                c2_ = x2.shape[-1] if x2 is not None else 0
+                xact = buf(*x1.shape[:4], c1_ + c2_)
+                Sx = x1.shape[1] * x1.shape[2] * x1.shape[3]
+                ga = (ptr(x1), c1_, ptr(x2), c2_, dtc, x1.shape[0], Sx, ptr(pre["a"]), ptr(pre["b"]), int(pre_silu), ptr(xact))
+                self.ops.append(lambda s, a=ga: L.rho_gn_apply(*a, s))
+                self.info.append(dict(kind="gn_apply", flops=0.0, bytes=2.0 * esz * xact.numel()))
+                cx1, cx2, cpre = xact, None, None
+            d = ops.make_conv_desc(cx1, cx2, cw.w, cw.b, kernel=cw.kernel, cout=cout, split=split_, y=y, y2=y2,
+                                   stride_hw=stride_hw, up_hw=up_hw, pre_a=cpre["a"] if cpre else None,
+                                   pre_b=cpre["b"] if cpre else None, pre_silu=pre_silu if cpre else False, res=res, res_add=None)
             if res_add_off is not None:
                 d.res_add = self.film.data_ptr() + 4 * res_add_off
                 d.res_add_stride = self.film.shape[1]
@@ -395,7 +411,8 @@ class _Plan:
                 flops=2.0 * npos_out * cout * cw.cin * cw.taps,                       # algorithmic (unpadded) MACs * 2
                 bytes=float(esz) * (npos_in * cw.cin + npos_out * cout * (2 if res is not None else 1) + cw.taps * cout * cw.cin)))
             self.nodes.append(dict(k="conv", cw=cw, x1=x1, x2=x2, y=y, y2=y2, stride_hw=stride_hw, up_hw=up_hw, pre=pre,
-                                   pre_silu=pre_silu, res=res, res_add_off=res_add_off, stem=stem, out_dims=(N, Do, Ho, Wo)))
+                                   pre_silu=pre_silu, res=res, res_add_off=res_add_off, stem=stem, out_dims=(N, Do, Ho, Wo),
+                                   xact=xact))
             return y, y2
 
         def resblock(blk, h1, h2):
@@ -540,7 +557,9 @@ class _Plan:
             pre = node["pre"]
             x2 = node["x2"]
             xact = None
-            if pre is not None:
+            if node.get("xact") is not None:
+                x1, x2 = node["xact"], None              # materialised by the forward plan
+            elif pre is not None:
                 # materialise act(a*x+b) once (HBM-rate) instead of redoing it in every (cout tile, cin chunk) workgroup
                 c1_ = x1.shape[-1]
                 c2_ = x2.shape[-1] if x2 is not None else 0
