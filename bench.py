@@ -134,18 +134,19 @@ def roofline_of(plan, args):
     # HBM traffic of the same launches from PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
     # --pmc passes; collected offline with rocprofv3 on this command, see profiles/): bench.py cannot run the profiler
     traffic = traffic_note = None
-    tpath = os.path.join(ROOT, "profiles", "r01b_pmc_traffic_conv3.json")
+    tpath = os.path.join(ROOT, "profiles", "r01d_pmc_traffic_conv3.json")
     if os.path.exists(tpath) and args.dtype == "bf16" and args.batch == 32 and args.grid == 64 and args.dims == 3 and args.mc == 64:
         with open(tpath) as f:
             tj = json.load(f)
-        traffic, traffic_note = tj["hbm_bytes_per_step"], "profiles/r01b_pmc_traffic_conv3.json (bytes per step over the same launches)"
+        traffic, traffic_note = tj["hbm_bytes_per_launch"], "profiles/r01d_pmc_traffic_conv3.json (PMC FETCH_SIZE x2 + WRITE_SIZE, average per launch of the same 52 launches)"
     alg_bytes = sum(p["bytes"] for p in conv3)
     return {
         "bound": "mfma", "kernel": "k_conv (3x3x3 implicit GEMM, LDS halo tile)", "achieved": achieved, "peak": peak,
         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_note,
-        "algorithmic_bytes_per_step": alg_bytes,
+        "algorithmic_bytes_per_launch": alg_bytes / max(1, len(conv3)), "algorithmic_flops_per_launch": fl / max(1, len(conv3)),
         "launches_per_step": len(conv3), "avg_launch_ms": ms / max(1, len(conv3)),
-        "algorithmic_flops_per_step": fl, "kernel_ms_per_step": ms, "all_kernels_ms_per_step": sum(p["ms"] for p in prof),
+        "algorithmic_bytes_per_step": alg_bytes, "algorithmic_flops_per_step": fl, "kernel_ms_per_step": ms,
+        "all_kernels_ms_per_step": sum(p["ms"] for p in prof),
         "by_kind_ms": {k: round(v["ms"], 3) for k, v in kinds.items()},
         "hbm_kernels_GBps": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in kinds.items()
                              if k in ("gn_partial", "pack") and v["ms"] > 0},
