@@ -114,6 +114,23 @@ class AbstractDiffusionPipeline(_Base):
             result[key] = self.reshape_timesteps(data, self.schedule[key].to(data.device)[t])
         return result
 
+    def _preembed_conditions(self, cc):
+        """Sampling evaluates the backbone T times with the SAME labels: run the label embedding (``cond_fn``, e.g.
+        MultiEmbeddings with its host-synchronising table lookup, conditioning.py:115-139) once and hand the UNet the
+        pre-embedded ``[B, 4*mc]`` form it also accepts (unet_v2.py:702-719).  Same arithmetic per step, no per-step host
+        sync, and the step stays capturable in a HIP graph."""
+        fn = getattr(self.backbone, "cond_fn", None)
+        mc = getattr(self.backbone, "model_channels", None)
+        if cc is None or fn is None or mc is None or not torch.is_tensor(cc):
+            return cc
+        if cc.dim() == 2 and cc.shape[1] == 4 * mc:
+            return cc
+        with torch.no_grad():
+            emb = fn(cc)
+        if emb.dim() == 2 and emb.shape[1] == 4 * mc:
+            return emb.float().contiguous()
+        return cc
+
     def forward_process(self, data: Tensor, t: Union[Tensor, None] = None):
         ...
 

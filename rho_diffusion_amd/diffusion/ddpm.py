@@ -115,6 +115,7 @@ class DDPM(AbstractDiffusionPipeline):
                 cc = torch.tensor(conditions).to(dev)
         else:
             cc = None
+        cc = self._preembed_conditions(cc)
 
         engine = self.backbone.engine() if hasattr(self.backbone, "engine") else None
         t_dev = torch.full((1,), denoise_steps - 1, dtype=torch.int32, device=dev)
