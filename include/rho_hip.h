@@ -265,6 +265,15 @@ int rho_ddim_step(const float* x_t, const float* model_out, const float* quantil
                   float* pred_xstart, int64_t batch, int64_t per_sample, float c_recip, float c_recipm1,
                   float sqrt_abar_prev, float coef_eps, float sigma_masked, void* stream);
 
+/* One reverse step of the diffusers-style DDPM scheduler the reference's DiffusersDDPMPipeline drives
+ * (rho_diffusion/diffusion/diffusers.py:214; published DDPMScheduler.step; PARITY UNPINNED - third-party arithmetic):
+ *   x0 = eps_mode ? (x_t - sqrt_beta_prod * model_out) / sqrt_alpha_prod : model_out;  clamp to +-clip when clip > 0;
+ *   x_prev = c0 * x0 + c1 * x_t + sigma * noise        (noise may be NULL when sigma == 0; pred_xstart may be NULL)
+ * float32, n elements, scalars prepared by the caller from the scheduler tables. */
+int rho_ddpm_sched_step(const float* x_t, const float* model_out, const float* noise, float* x_prev, float* pred_xstart,
+                        int64_t n, int eps_mode, float sqrt_beta_prod, float sqrt_alpha_prod, float clip, float c0, float c1,
+                        float sigma, void* stream);
+
 /* Channel sums of a channels-last tensor (conv bias gradients; additive-embedding gradients):
  * out_nc[n*nc_stride + c] (+)= sum_pos x[n,pos,c];  out_c[c] (+)= sum_n out_nc[n][c] (optional).
  * partials: scratch sized like rho_gn_partial's. */

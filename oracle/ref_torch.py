@@ -440,6 +440,75 @@ def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float,
 
 
 # --------------------------------------------------------------------------- inputs
+# --------------------------------------------------------------------------- diffusers.DDPMScheduler subset
+# PARITY UNPINNED: the arithmetic lives in the third-party `diffusers` package, which the reference leaves unpinned
+# (pyproject.toml) and which is not installed here; this restates the published DDPMScheduler algorithm
+# (scheduling_ddpm.py: betas_for_alpha_bar / rescale_zero_terminal_snr / add_noise / step / _get_variance) for the
+# configuration scripts/training.py:85-95 builds and the call sites rho_diffusion/diffusion/diffusers.py:146-227.
+def dds_tables(num_train_timesteps: int = 1000, beta_schedule: str = "squaredcos_cap_v2", rescale_betas_zero_snr: bool = False,
+               beta_start: float = 1e-4, beta_end: float = 0.02) -> Dict[str, Tensor]:
+    if beta_schedule == "linear":
+        betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+    elif beta_schedule == "squaredcos_cap_v2":
+        ab = lambda t: math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2
+        betas = torch.tensor([min(1 - ab((i + 1) / num_train_timesteps) / ab(i / num_train_timesteps), 0.999)
+                              for i in range(num_train_timesteps)], dtype=torch.float32)
+    else:
+        raise NotImplementedError(beta_schedule)
+    if rescale_betas_zero_snr:                     # rescale_zero_terminal_snr
+        alphas = 1.0 - betas
+        abs_ = torch.cumprod(alphas, dim=0).sqrt()
+        a0, aT = abs_[0].clone(), abs_[-1].clone()
+        abs_ = (abs_ - aT) * (a0 / (a0 - aT))
+        abar = abs_ ** 2
+        alphas = torch.cat([abar[0:1], abar[1:] / abar[:-1]])
+        betas = 1 - alphas
+    alphas = 1.0 - betas
+    return {"betas": betas, "alphas": alphas, "alphas_cumprod": torch.cumprod(alphas, dim=0)}
+
+
+def dds_add_noise(tab, x0: Tensor, noise: Tensor, t: Tensor) -> Tensor:
+    ac = tab["alphas_cumprod"]
+    a = (ac[t] ** 0.5).flatten()
+    b = ((1 - ac[t]) ** 0.5).flatten()
+    while a.dim() < x0.dim():
+        a, b = a.unsqueeze(-1), b.unsqueeze(-1)
+    return a * x0 + b * noise
+
+
+def dds_step(tab, model_output: Tensor, t: int, sample: Tensor, noise: Tensor, prediction_type: str = "epsilon",
+             variance_type: str = "fixed_large", clip_sample: bool = True, clip_sample_range: float = 1.0):
+    """DDPMScheduler.step for num_inference_steps = None (prev_t = t - 1); returns (prev_sample, pred_original_sample)."""
+    ac = tab["alphas_cumprod"]
+    one = torch.tensor(1.0)
+    alpha_prod_t = ac[t]
+    alpha_prod_t_prev = ac[t - 1] if t - 1 >= 0 else one
+    beta_prod_t = 1 - alpha_prod_t
+    beta_prod_t_prev = 1 - alpha_prod_t_prev
+    current_alpha_t = alpha_prod_t / alpha_prod_t_prev
+    current_beta_t = 1 - current_alpha_t
+    if prediction_type == "epsilon":
+        x0 = (sample - beta_prod_t ** 0.5 * model_output) / alpha_prod_t ** 0.5
+    elif prediction_type == "sample":
+        x0 = model_output
+    else:
+        raise NotImplementedError(prediction_type)
+    if clip_sample:
+        x0 = x0.clamp(-clip_sample_range, clip_sample_range)
+    c0 = (alpha_prod_t_prev ** 0.5 * current_beta_t) / beta_prod_t
+    c1 = current_alpha_t ** 0.5 * beta_prod_t_prev / beta_prod_t
+    prev = c0 * x0 + c1 * sample
+    if t > 0:
+        var = (1 - alpha_prod_t_prev) / (1 - alpha_prod_t) * current_beta_t
+        var = torch.clamp(var, min=1e-20)
+        if variance_type == "fixed_large":
+            var = current_beta_t
+        elif variance_type != "fixed_small":
+            raise NotImplementedError(variance_type)
+        prev = prev + (var ** 0.5) * noise
+    return prev, x0
+
+
 def ema_update(shadow: Tensor, param: Tensor, step_id: int, decay: float = 0.9999) -> float:
     """ExponentialMovingAverage.update for one tensor, in place (rho_diffusion/ema.py:41-60); returns the fraction."""
     frac = decay * (1 - math.exp(-step_id / 2000))

@@ -214,3 +214,47 @@ extern "C" int rho_q_sample_coef(const float* x0, const float* eps, float* x_t, 
     RHO_LAUNCH_CHECK();
     return 0;
 }
+
+// One reverse step of the diffusers-style DDPM scheduler (call site rho_diffusion/diffusion/diffusers.py:214,
+// published DDPMScheduler.step), float32, operation order of the published tensor expressions, no contraction:
+//   x0 = eps_mode ? (x - sqrt_beta_prod * m) / sqrt_alpha_prod : m;   x0 = clamp(x0, -clip, clip) if clip > 0
+//   x_prev = c0 * x0 + c1 * x  (+ sigma * noise when sigma != 0)
+// A terminal-SNR-zero schedule has sqrt_alpha_prod = 0 at t = T-1: the division yields +-inf, which the clamp maps to
+// +-clip exactly as the tensor expression does.
+__global__ __launch_bounds__(256) void k_ddpm_sched_step(const float* __restrict__ x, const float* __restrict__ m,
+                                                         const float* __restrict__ noise, float* __restrict__ x_prev,
+                                                         float* __restrict__ pred_x0, int64_t total, int eps_mode, float sqrt_beta_prod,
+                                                         float sqrt_alpha_prod, float clip, float c0, float c1, float sigma) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float x0 = m[i];
+        const float xi = x[i];
+        if (eps_mode) {
+            const float bm = sqrt_beta_prod * x0;
+            const float d = xi - bm;
+            x0 = d / sqrt_alpha_prod;
+        }
+        if (clip > 0.0f) x0 = fminf(fmaxf(x0, -clip), clip);
+        const float p0 = c0 * x0, p1 = c1 * xi;
+        float v = p0 + p1;
+        if (noise != nullptr) {
+            const float p2 = sigma * noise[i];
+            v = v + p2;
+        }
+        x_prev[i] = v;
+        if (pred_x0 != nullptr) pred_x0[i] = x0;
+    }
+}
+
+extern "C" int rho_ddpm_sched_step(const float* x_t, const float* model_out, const float* noise, float* x_prev, float* pred_xstart,
+                                   int64_t n, int eps_mode, float sqrt_beta_prod, float sqrt_alpha_prod, float clip, float c0,
+                                   float c1, float sigma, void* stream) {
+    if (!x_t || !model_out || !x_prev || n <= 0) return RHO_E_ARG;
+    if (sigma != 0.0f && !noise) return RHO_E_ARG;
+    int64_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_ddpm_sched_step, dim3((unsigned)g), dim3(256), 0, as_stream(stream), x_t, model_out,
+                       (sigma != 0.0f) ? noise : nullptr, x_prev, pred_xstart, n, eps_mode, sqrt_beta_prod, sqrt_alpha_prod, clip, c0, c1,
+                       sigma);
+    RHO_LAUNCH_CHECK();
+    return 0;
+}

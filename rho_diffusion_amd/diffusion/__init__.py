@@ -3,3 +3,4 @@ from .schedule import LinearSchedule, CosineBetaSchedule, SigmoidSchedule  # noq
 from .abstract_diffusion import AbstractDiffusionPipeline  # noqa: F401
 from .ddpm import DDPM  # noqa: F401
 from .gaussian_diffusion import GaussianDiffusionPipeline  # noqa: F401
+from .diffusers_ddpm import DDPMScheduler, DiffusersDDPMPipeline  # noqa: F401

@@ -70,6 +70,8 @@ SIGNATURES = {
     "rho_gn_bwd_apply": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "rho_gn_apply": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "rho_ddpm_sched_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_float,
+                                    c_float, c_float, c_void_p]),
     "rho_ema_update": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
     "rho_abs_quantile_workspace_bytes": (c_int64, [c_int64]),
     "rho_abs_quantile": (c_int, [c_void_p, c_int64, c_int64, c_double, c_void_p, c_void_p, c_void_p]),

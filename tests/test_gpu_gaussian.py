@@ -125,3 +125,45 @@ def test_reverse_process_philox_is_reproducible_and_bounded():
     b = pipe.reverse_process(torch.zeros(xshape, device=DEV))["denoised"]
     assert torch.equal(a, b)
     assert float(a.abs().max()) <= 1.0 + 1e-6           # the last step (abar_prev = 1) returns the thresholded x0 itself
+
+
+@pytest.mark.parametrize("pred,var", [("epsilon", "fixed_large"), ("sample", "fixed_small")])
+def test_diffusers_style_scheduler_vs_oracle(pred, var):
+    """DDPMScheduler / rho_ddpm_sched_step (PARITY UNPINNED: third-party arithmetic restated from the published
+    algorithm) against the oracle's restatement: tables equal, add_noise and steps incl. the zero-terminal-SNR first step
+    (division by sqrt(abar) = 0 -> +-inf -> clamp) within 1 ulp, x0 clamp exact."""
+    from rho_diffusion_amd.diffusion import DDPMScheduler
+    T = 100
+    sch = DDPMScheduler(num_train_timesteps=T, beta_schedule="squaredcos_cap_v2", prediction_type=pred, variance_type=var,
+                        clip_sample=True, clip_sample_range=0.5, rescale_betas_zero_snr=True)
+    tab = R.dds_tables(T, "squaredcos_cap_v2", True)
+    assert torch.equal(sch.alphas_cumprod, tab["alphas_cumprod"]) and float(sch.alphas_cumprod[-1]) == 0.0
+    shape = (3, 2, 6, 10)
+    x, m, nz = det_normal(shape, "dds_x"), det_normal(shape, "dds_m"), det_normal(shape, "dds_n")
+    tq = torch.tensor([0, 57, T - 1])
+    got = sch.add_noise(x.to(DEV), nz.to(DEV), tq.to(DEV)).cpu()
+    assert torch.allclose(got, R.dds_add_noise(tab, x, nz, tq), rtol=3e-7, atol=3e-7)
+    for t in (T - 1, 57, 1, 0):
+        ref, ref_x0 = R.dds_step(tab, m, t, x, nz, prediction_type=pred, variance_type=var, clip_sample=True, clip_sample_range=0.5)
+        out = sch.step(m.to(DEV), t, x.to(DEV), noise=nz.to(DEV))
+        assert torch.isfinite(out["prev_sample"]).all(), t
+        assert torch.allclose(out["pred_original_sample"].cpu(), ref_x0, rtol=3e-7, atol=3e-7), t
+        assert torch.allclose(out["prev_sample"].cpu(), ref, rtol=1e-6, atol=1e-6), (t, float((out["prev_sample"].cpu() - ref).abs().max()))
+    assert float(out["pred_original_sample"].abs().max()) <= 0.5
+
+
+def test_diffusers_style_pipeline_reverse_process_runs():
+    from rho_diffusion_amd.diffusion import DDPMScheduler, DiffusersDDPMPipeline
+    from rho_diffusion_amd.models import UNet
+    g4 = load_golden("g4_unet.npz")
+    case = "tiny2d"
+    kw, xshape, _ = UNET_CASES[case]
+    sch = DDPMScheduler(num_train_timesteps=20, beta_schedule="squaredcos_cap_v2", prediction_type="epsilon",
+                        variance_type="fixed_large", clip_sample=True, clip_sample_range=0.5, rescale_betas_zero_snr=True)
+    pipe = DiffusersDDPMPipeline(UNet, dict(kw, compute_dtype="bf16"), sch, nn.MSELoss, timesteps=20)
+    pipe.backbone.load_state_dict(det_state_dict(golden_template(g4, case), case))
+    pipe = pipe.to(DEV)
+    res = pipe.reverse_process(torch.zeros(xshape, device=DEV), None, t_checkpoints=[0, 1])
+    assert torch.isfinite(res["denoised"]).all() and res["buffer"].shape[1] == 2
+    xt, nz = pipe.forward_process(det_uniform(xshape, "dp_x0", -0.5, 0.5).to(DEV), torch.tensor([0, 19]))
+    assert torch.isfinite(xt).all() and xt.shape == tuple(xshape) and float((xt[1] - nz[1]).abs().max()) < 1e-6   # abar[T-1] = 0

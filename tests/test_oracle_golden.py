@@ -207,3 +207,18 @@ def test_g10_ema():
         assert frac == float(g[f"frac{step}"])
         for k in shadow:
             assert torch.equal(shadow[k], torch.from_numpy(g[f"s{step}/{k}"])), (step, k)
+
+
+def test_dds_oracle_properties():
+    """diffusers-style scheduler restatement (PARITY UNPINNED: no reference vectors exist for it): structural properties."""
+    tab = R.dds_tables(1000, "squaredcos_cap_v2", True)
+    ac = tab["alphas_cumprod"]
+    assert float(ac[-1]) == 0.0 and bool((ac[1:] <= ac[:-1]).all()) and 0.999 < float(ac[0]) < 1.0
+    plain = R.dds_tables(1000, "squaredcos_cap_v2", False)
+    assert float(plain["betas"].max()) == pytest.approx(0.999) and float(plain["alphas_cumprod"][-1]) > 0.0
+    x, e, n = det_normal((2, 1, 4, 4), "ddsx"), det_normal((2, 1, 4, 4), "ddse"), det_normal((2, 1, 4, 4), "ddsn")
+    p0, x0 = R.dds_step(tab, e, 0, x, n, clip_sample_range=0.5)
+    p0b, _ = R.dds_step(tab, e, 0, x, 2 * n, clip_sample_range=0.5)
+    assert torch.equal(p0, p0b) and float(x0.abs().max()) <= 0.5          # no noise at t = 0; clamp
+    pT, xT = R.dds_step(tab, e, 999, x, n, clip_sample_range=0.5)
+    assert torch.isfinite(pT).all() and bool((xT.abs() == 0.5).all())     # +-inf clamps to the range at zero terminal SNR

@@ -1,5 +1,9 @@
 """Timing probe (not a product path): rho_conv_nd_fwd from debug builds of conv.hip with parts compiled out
-(RHO_DBG bits: 1 no epilogue, 2 no halo global loads, 4 no prologue, 8 no weight global loads, 16 no MFMA)."""
+(RHO_DBG bits: 1 no epilogue, 2 no halo global loads, 4 no prologue, 8 no weight global loads, 16 no MFMA).
+The debug libraries (tools/probe/libconv_dbg<bits>.so, not kept in the tree) were built from a scratch copy of conv.hip
+with `if (RHO_DBG & bit)` guards around the halo loads, apply_pre, the weight loads, the MFMA calls and the epilogue
+(stores kept behind an impossible runtime condition so nothing is dead code): hipcc -DRHO_DBG=<bits> -shared -fPIC.
+Results of the run that guided round 1 are quoted in DESIGN.md section 5."""
 import ctypes as C, glob, os, sys, time
 R0 = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R0)
