@@ -10,4 +10,10 @@ reference ``file:line`` it follows.  It is pinned by golden vectors generated fr
 the reference itself in the build container (``tests/golden/make_golden.py`` ->
 ``tests/golden/*.npz``) and by the reference's only known-answer test
 (``tests/pipeline/test_schedule.py:28-46``); see ``tests/test_oracle_golden.py``.
+
+Pinned: schedules, embeddings, UNetv2 modules / forward / gradients, DDPM loops, AdamW (g1-g8), the
+GaussianDiffusionPipeline sampling path (g9), ExponentialMovingAverage (g10).
+PARITY UNPINNED: the ``dds_*`` functions (diffusers-style DDPMScheduler of ``DiffusersDDPMPipeline``): that arithmetic
+lives in the third-party ``diffusers`` package (unpinned in the reference's pyproject, not installed here); they restate
+the published scheduler and are checked for structure only.
 """
