@@ -21,29 +21,35 @@ struct ET<float> {
 template <typename T>
 __device__ __forceinline__ uint4 apply_pre(uint4 v, const float* __restrict__ a, const float* __restrict__ b, int silu);
 
+// bf16: two channels per operation with the packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, full
+// rate on CDNA3/4); the same operation sequence per element as the scalar form (fma; then x * rcp(1 + exp2(-log2e * x)) as
+// silu_f), so results are bit-identical to k_gn_apply.  44 instead of 60 VALU instructions per 16-byte piece: the loader's
+// prologue competes with the MFMA issue of the other wave on the SIMD.
 template <>
 __device__ __forceinline__ uint4 apply_pre<bf16_raw>(uint4 v, const float* __restrict__ a, const float* __restrict__ b, int silu) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
     const float4 a0 = *reinterpret_cast<const float4*>(a), a1 = *reinterpret_cast<const float4*>(a + 4);
     const float4 b0 = *reinterpret_cast<const float4*>(b), b1 = *reinterpret_cast<const float4*>(b + 4);
-    float f[8];
-    f[0] = fmaf(a0.x, __uint_as_float(v.x << 16), b0.x);
-    f[1] = fmaf(a0.y, __uint_as_float(v.x & 0xFFFF0000u), b0.y);
-    f[2] = fmaf(a0.z, __uint_as_float(v.y << 16), b0.z);
-    f[3] = fmaf(a0.w, __uint_as_float(v.y & 0xFFFF0000u), b0.w);
-    f[4] = fmaf(a1.x, __uint_as_float(v.z << 16), b1.x);
-    f[5] = fmaf(a1.y, __uint_as_float(v.z & 0xFFFF0000u), b1.y);
-    f[6] = fmaf(a1.z, __uint_as_float(v.w << 16), b1.z);
-    f[7] = fmaf(a1.w, __uint_as_float(v.w & 0xFFFF0000u), b1.w);
-    if (silu) {
+    const f32x2_t av[4] = {{a0.x, a0.y}, {a0.z, a0.w}, {a1.x, a1.y}, {a1.z, a1.w}};
+    const f32x2_t bv[4] = {{b0.x, b0.y}, {b0.z, b0.w}, {b1.x, b1.y}, {b1.z, b1.w}};
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t r[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
+    for (int j = 0; j < 4; ++j) {
+        const f32x2_t x = {__uint_as_float(w[j] << 16), __uint_as_float(w[j] & 0xFFFF0000u)};
+        f32x2_t y = __builtin_elementwise_fma(av[j], x, bv[j]);
+        if (silu) {
+            const f32x2_t t = y * -1.4426950408889634f;
+            const f32x2_t e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+            const f32x2_t d = e + 1.0f;                      // 1 + exp2(.) == exp2(.) + 1 (commutative, one rounding)
+            const f32x2_t q = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+            y = y * q;
+        }
+        const bf16x2_t h = {(__bf16)y.x, (__bf16)y.y};
+        r[j] = __builtin_bit_cast(uint32_t, h);
     }
-    uint4 r;
-    r.x = pack_bf16x2(f[0], f[1]);
-    r.y = pack_bf16x2(f[2], f[3]);
-    r.z = pack_bf16x2(f[4], f[5]);
-    r.w = pack_bf16x2(f[6], f[7]);
-    return r;
+    return make_uint4(r[0], r[1], r[2], r[3]);
 }
 
 template <>
