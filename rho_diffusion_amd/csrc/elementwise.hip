@@ -459,30 +459,58 @@ extern "C" int rho_upsample2x(const void* x, void* y, int dtype, int64_t n_times
 template <typename T>
 __global__ __launch_bounds__(256) void k_pool2x_sum(const T* __restrict__ dy, T* __restrict__ dx, int64_t nd, int h, int w, int c,
                                                     int uh, int uw, int accumulate) {
+    // one 16-byte channel piece per thread (the scalar form ran at 1.8 TB/s)
+    constexpr int PE = 16 / (int)sizeof(T);
     const int ho = uh ? 2 * h : h, wo = uw ? 2 * w : w;
-    const int64_t total = nd * h * w * c;
+    const int cp = c / PE;
+    const int64_t total = nd * h * w * cp;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(i % c);
-        int64_t r = i / c;
+        const int pc = (int)(i % cp);
+        int64_t r = i / cp;
         const int iw = (int)(r % w); r /= w;
         const int ih = (int)(r % h); r /= h;
-        float acc = 0.0f;
+        float acc[PE];
+#pragma unroll
+        for (int e = 0; e < PE; ++e) acc[e] = 0.0f;
         for (int a = 0; a <= uh; ++a)
             for (int b = 0; b <= uw; ++b) {
-                const int64_t o = ((r * ho + (uh ? 2 * ih + a : ih)) * wo + (uw ? 2 * iw + b : iw)) * c + ch;
-                if constexpr (sizeof(T) == 2) acc += bf16_to_f32(dy[o]); else acc += dy[o];
+                const int64_t o = ((r * ho + (uh ? 2 * ih + a : ih)) * wo + (uw ? 2 * iw + b : iw)) * c + pc * PE;
+                const uint4 u = *reinterpret_cast<const uint4*>(dy + o);
+                if constexpr (sizeof(T) == 2) {
+                    acc[0] += __uint_as_float(u.x << 16); acc[1] += __uint_as_float(u.x & 0xFFFF0000u);
+                    acc[2] += __uint_as_float(u.y << 16); acc[3] += __uint_as_float(u.y & 0xFFFF0000u);
+                    acc[4] += __uint_as_float(u.z << 16); acc[5] += __uint_as_float(u.z & 0xFFFF0000u);
+                    acc[6] += __uint_as_float(u.w << 16); acc[7] += __uint_as_float(u.w & 0xFFFF0000u);
+                } else {
+                    acc[0] += __uint_as_float(u.x); acc[1] += __uint_as_float(u.y); acc[2] += __uint_as_float(u.z); acc[3] += __uint_as_float(u.w);
+                }
             }
+        T* dst = dx + (i / cp) * c + pc * PE;
         if (accumulate) {
-            if constexpr (sizeof(T) == 2) acc += bf16_to_f32(dx[i]); else acc += dx[i];
+            const uint4 u = *reinterpret_cast<const uint4*>(dst);
+            if constexpr (sizeof(T) == 2) {
+                acc[0] += __uint_as_float(u.x << 16); acc[1] += __uint_as_float(u.x & 0xFFFF0000u);
+                acc[2] += __uint_as_float(u.y << 16); acc[3] += __uint_as_float(u.y & 0xFFFF0000u);
+                acc[4] += __uint_as_float(u.z << 16); acc[5] += __uint_as_float(u.z & 0xFFFF0000u);
+                acc[6] += __uint_as_float(u.w << 16); acc[7] += __uint_as_float(u.w & 0xFFFF0000u);
+            } else {
+                acc[0] += __uint_as_float(u.x); acc[1] += __uint_as_float(u.y); acc[2] += __uint_as_float(u.z); acc[3] += __uint_as_float(u.w);
+            }
         }
-        dx[i] = cvt_out<T>(acc);
+        if constexpr (sizeof(T) == 2)
+            *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]),
+                                                        pack_bf16x2(acc[6], acc[7]));
+        else
+            *reinterpret_cast<uint4*>(dst) = make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]),
+                                                        __float_as_uint(acc[3]));
     }
 }
 
 extern "C" int rho_pool2x_sum(const void* dy, void* dx, int dtype, int64_t n_times_d, int64_t h, int64_t w, int64_t c, int up_h,
                               int up_w, int accumulate, void* stream) {
     if (!dy || !dx || n_times_d <= 0 || h <= 0 || w <= 0 || c <= 0) return RHO_E_ARG;
-    dim3 grid(grid_for(n_times_d * h * w * c, 256)), block(256);
+    if (c % 8 != 0) return RHO_E_ALIGN;
+    dim3 grid(grid_for(n_times_d * h * w * (c / (dtype == RHO_BF16 ? 8 : 4)), 256)), block(256);
     if (dtype == RHO_BF16)
         hipLaunchKernelGGL(k_pool2x_sum<bf16_raw>, grid, block, 0, as_stream(stream), (const bf16_raw*)dy, (bf16_raw*)dx, n_times_d, (int)h,
                            (int)w, (int)c, up_h, up_w, accumulate);
