@@ -418,7 +418,8 @@ extern "C" int rho_gn_bwd_reduce(const void* g, const void* x1, int64_t c1, cons
     return 0;
 }
 
-// one block per sample: totals, group sums, per-sample parameter-gradient rows and apply coefficients
+// grid (n, 8): a workgroup owns 4 groups (4 * cpg <= 256 channels) of one sample: totals over the position blocks (KP
+// lanes per channel, fixed order), group sums, per-sample parameter-gradient rows and the apply coefficients
 __global__ __launch_bounds__(256) void k_gn_bwd_finalize(const float* __restrict__ partials, int c, int64_t s, int nblk,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ scale, int64_t film_stride,
@@ -426,55 +427,78 @@ __global__ __launch_bounds__(256) void k_gn_bwd_finalize(const float* __restrict
                                                          float* __restrict__ dbeta_n, float* __restrict__ dscale,
                                                          float* __restrict__ dshift, int64_t dfilm_stride,
                                                          float* __restrict__ cA, float* __restrict__ cP, float* __restrict__ cQ) {
-    __shared__ float r1s[2048], r2s[2048];
-    __shared__ float s1g[32], s2g[32];
-    const int n = blockIdx.x, tid = threadIdx.x;
+    __shared__ double l1[256], l2[256];
+    __shared__ float r1s[256], r2s[256];
+    const int n = blockIdx.x, gq = blockIdx.y, tid = threadIdx.x;
     const int OCT = c >> 3;
     const int cpg = c / 32;
-    for (int ch = tid; ch < c; ch += 256) {
+    const int CB = 4 * cpg;
+    const int ch0 = gq * CB;
+    int KP = 256 / CB;
+    if (KP < 1) KP = 1;
+    const int cl = tid % CB, kp = tid / CB;
+    double a1 = 0.0, a2 = 0.0;
+    if (kp < KP) {
+        const int ch = ch0 + cl;
         const int o = ch >> 3, j = ch & 7;
-        double a1 = 0.0, a2 = 0.0;
-        for (int k = 0; k < nblk; ++k) {
+        for (int k = kp; k < nblk; k += KP) {
             const float* p = partials + (((int64_t)n * nblk + k) * OCT + o) * 16;
             a1 += (double)p[j];
             a2 += (double)p[8 + j];
         }
-        r1s[ch] = (float)a1;
-        r2s[ch] = (float)a2;
+    }
+    l1[tid] = a1;
+    l2[tid] = a2;
+    __syncthreads();
+    if (tid < CB) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int q = 0; q < KP; ++q) { t1 += l1[q * CB + tid]; t2 += l2[q * CB + tid]; }
+        r1s[tid] = (float)t1;
+        r2s[tid] = (float)t2;
     }
     __syncthreads();
-    if (tid < 32) {
+    if (tid < 4) {
+        const int g = gq * 4 + tid;
         double s1 = 0.0, s2 = 0.0;
         for (int k = 0; k < cpg; ++k) {
-            const int ch = tid * cpg + k;
+            const int ch = g * cpg + k;
             const float gp = gamma[ch] * (scale ? 1.0f + scale[(int64_t)n * film_stride + ch] : 1.0f);
-            s1 += (double)gp * r1s[ch];
-            s2 += (double)gp * r2s[ch];
+            s1 += (double)gp * r1s[tid * cpg + k];
+            s2 += (double)gp * r2s[tid * cpg + k];
         }
-        s1g[tid] = (float)s1;
-        s2g[tid] = (float)s2;
-        const float mean = stats[((int64_t)n * 32 + tid) * 2 + 0];
-        const float rstd = stats[((int64_t)n * 32 + tid) * 2 + 1];
+        const float mean = stats[((int64_t)n * 32 + g) * 2 + 0];
+        const float rstd = stats[((int64_t)n * 32 + g) * 2 + 1];
         const double M = (double)cpg * (double)s;
-        cP[(int64_t)n * 32 + tid] = (float)(-(double)rstd * s1 / M + (double)rstd * rstd * s2 * mean / M);
-        cQ[(int64_t)n * 32 + tid] = (float)(-(double)rstd * rstd * s2 / M);
+        cP[(int64_t)n * 32 + g] = (float)(-(double)rstd * s1 / M + (double)rstd * rstd * s2 * mean / M);
+        cQ[(int64_t)n * 32 + g] = (float)(-(double)rstd * rstd * s2 / M);
     }
-    __syncthreads();
-    for (int ch = tid; ch < c; ch += 256) {
+    if (tid < CB) {
+        const int ch = ch0 + tid;
         const int grp = ch / cpg;
         const float rstd = stats[((int64_t)n * 32 + grp) * 2 + 1];
         const float sc = scale ? 1.0f + scale[(int64_t)n * film_stride + ch] : 1.0f;
         cA[(int64_t)n * c + ch] = rstd * gamma[ch] * sc;
-        dgamma_n[(int64_t)n * c + ch] = r2s[ch] * sc;
-        dbeta_n[(int64_t)n * c + ch] = r1s[ch] * sc;
+        dgamma_n[(int64_t)n * c + ch] = r2s[tid] * sc;
+        dbeta_n[(int64_t)n * c + ch] = r1s[tid] * sc;
         if (dscale) {
-            dscale[(int64_t)n * dfilm_stride + ch] = gamma[ch] * r2s[ch] + beta[ch] * r1s[ch];
-            dshift[(int64_t)n * dfilm_stride + ch] = r1s[ch];
+            dscale[(int64_t)n * dfilm_stride + ch] = gamma[ch] * r2s[tid] + beta[ch] * r1s[tid];
+            dshift[(int64_t)n * dfilm_stride + ch] = r1s[tid];
         }
     }
 }
 
-// out[c] (+)= sum_n in[n][c]   (deterministic order)
+// out[c] (+)= sum_n in[n][c]   (deterministic order); blockIdx.y selects the (in, out) pair
+__global__ void k_sum_over_n2(const float* __restrict__ in0, float* __restrict__ out0, const float* __restrict__ in1,
+                              float* __restrict__ out1, int n, int c, int accumulate) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    const float* in = blockIdx.y ? in1 : in0;
+    float* out = blockIdx.y ? out1 : out0;
+    float acc = 0.0f;
+    for (int k = 0; k < n; ++k) acc += in[(int64_t)k * c + ch];
+    out[ch] = accumulate ? out[ch] + acc : acc;
+}
+
 __global__ void k_sum_over_n(const float* __restrict__ in, float* __restrict__ out, int n, int c, int accumulate) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= c) return;
@@ -492,13 +516,12 @@ extern "C" int rho_gn_bwd_finalize(const float* partials, int64_t n, int64_t c, 
         return RHO_E_ARG;
     float* dg_n = work_nc2;
     float* db_n = work_nc2 + n * c;
-    hipLaunchKernelGGL(k_gn_bwd_finalize, dim3((unsigned)n), dim3(256), 0, as_stream(stream), partials, (int)c, s, (int)nblk, gamma,
+    if (n > 65535) return RHO_E_SHAPE;
+    hipLaunchKernelGGL(k_gn_bwd_finalize, dim3((unsigned)n, 8), dim3(256), 0, as_stream(stream), partials, (int)c, s, (int)nblk, gamma,
                        beta, scale, film_stride, stats, dg_n, db_n, dscale, dshift, dfilm_stride, cA, cP, cQ);
     RHO_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sum_over_n, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, as_stream(stream), dg_n, dgamma, (int)n,
-                       (int)c, accumulate);
-    hipLaunchKernelGGL(k_sum_over_n, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, as_stream(stream), db_n, dbeta, (int)n,
-                       (int)c, accumulate);
+    hipLaunchKernelGGL(k_sum_over_n2, dim3((unsigned)((c + 255) / 256), 2), dim3(256), 0, as_stream(stream), dg_n, dgamma, db_n, dbeta,
+                       (int)n, (int)c, accumulate);
     RHO_LAUNCH_CHECK();
     return 0;
 }
