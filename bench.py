@@ -222,7 +222,7 @@ def main():
             try:
                 sample_step()                                   # builds the engine plan outside the capture
                 g_ = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_):
+                with torch.cuda.graph(g_, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) stay free to call HIP
                     sample_step()
                 step_fn, graphed = g_.replay, True
             except Exception as exc:  # noqa: BLE001

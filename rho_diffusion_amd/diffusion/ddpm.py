@@ -170,7 +170,7 @@ class DDPM(AbstractDiffusionPipeline):
             step()                                      # t = T-1, eager
             checkpoint(denoise_steps - 1)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may call HIP
                 step()
         except Exception as exc:  # noqa: BLE001  (capture is an optimisation; any failure -> eager loop)
             torch.cuda.synchronize()
