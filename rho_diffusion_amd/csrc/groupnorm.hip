@@ -215,16 +215,17 @@ __global__ __launch_bounds__(256) void k_gn_finalize2(const float* __restrict__ 
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ scale, const float* __restrict__ shift,
                                                       int64_t film_stride, float* __restrict__ stats, float* __restrict__ a,
-                                                      float* __restrict__ b) {
-    // grid (n, 8): a workgroup owns 4 of the 32 groups = 4 * cpg consecutive channels (<= 256), so every CU has work
-    // and a thread sums nblk / KP partials instead of all of them (74 us -> a few us per GroupNorm at 1024 tiles)
+                                                      float* __restrict__ b, int gpb) {
+    // grid (n, 32 / gpb): a workgroup owns gpb (4, or 1 for small batches) of the 32 groups = gpb * cpg consecutive
+    // channels (<= 256), so every CU has work and a thread sums nblk / KP partials instead of all of them
+    // (74 us -> a few us per GroupNorm at 1024 tiles)
     __shared__ double ls[256], lq[256];
     __shared__ double chs[256], chq[256];
     __shared__ float gmean[4], grstd[4];
     const int n = blockIdx.x, gq = blockIdx.y, tid = threadIdx.x;
     const int c = c1 + c2;
     const int cpg = c / 32;
-    const int CB = 4 * cpg;                      // channels of this workgroup
+    const int CB = gpb * cpg;                    // channels of this workgroup
     const int ch0 = gq * CB;
     int KP = 256 / CB;                           // lanes per channel
     if (KP < 1) KP = 1;
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256) void k_gn_finalize2(const float* __restrict__ 
         chq[tid] = tq;
     }
     __syncthreads();
-    if (tid < 4) {
+    if (tid < gpb) {
         double gu = 0.0, gs = 0.0;
         for (int k = 0; k < cpg; ++k) {
             gu += chs[tid * cpg + k];
@@ -262,8 +263,8 @@ __global__ __launch_bounds__(256) void k_gn_finalize2(const float* __restrict__ 
         gmean[tid] = (float)mean;
         grstd[tid] = rstd;
         if (stats) {
-            stats[((int64_t)n * 32 + gq * 4 + tid) * 2 + 0] = (float)mean;
-            stats[((int64_t)n * 32 + gq * 4 + tid) * 2 + 1] = rstd;
+            stats[((int64_t)n * 32 + gq * gpb + tid) * 2 + 0] = (float)mean;
+            stats[((int64_t)n * 32 + gq * gpb + tid) * 2 + 1] = rstd;
         }
     }
     __syncthreads();
@@ -292,8 +293,9 @@ extern "C" int rho_gn_finalize2(const float* p1, int fmt1, int64_t nblk1, int64_
     if (c % 32 != 0 || c > 2048 || c1 % 8 != 0 || c2 % 8 != 0 || (p2 && nblk2 <= 0)) return RHO_E_ARG;
     if ((fmt1 != 0 && fmt1 != 1) || (p2 && fmt2 != 0 && fmt2 != 1)) return RHO_E_ARG;
     if (n > 65535) return RHO_E_SHAPE;
-    hipLaunchKernelGGL(k_gn_finalize2, dim3((unsigned)n, 8), dim3(256), 0, as_stream(stream), p1, fmt1, (int)nblk1, (int)c1, p2, fmt2,
-                       (int)nblk2, (int)c2, s, gamma, beta, scale, shift, film_stride, stats, a, b);
+    const int gpb = (n * 8 >= 256) ? 4 : 1;      // small batches: one group per workgroup (32 per sample)
+    hipLaunchKernelGGL(k_gn_finalize2, dim3((unsigned)n, (unsigned)(32 / gpb)), dim3(256), 0, as_stream(stream), p1, fmt1, (int)nblk1,
+                       (int)c1, p2, fmt2, (int)nblk2, (int)c2, s, gamma, beta, scale, shift, film_stride, stats, a, b, gpb);
     RHO_LAUNCH_CHECK();
     return 0;
 }

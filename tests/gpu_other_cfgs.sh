@@ -1,4 +1,9 @@
 mkdir -p gpurun_out
-timeout -k 10 300 python bench.py --mode sample --dims 2 --grid 64 --mc 64 --batch 16 --dtype bf16 --steps 50 --warmup 5 --no-cpu-baseline --no-roofline > gpurun_out/cfg_c1g.log 2>&1; echo "c1 graph exit $?"; grep -o '"value": [0-9.]*, "unit": "steps/s"[^}]*"ms_per_step": [0-9.]*' gpurun_out/cfg_c1g.log | head -1; grep -o '"hip_graph": [a-z]*' gpurun_out/cfg_c1g.log
-timeout -k 10 300 python bench.py --mode sample --no-graph --dims 2 --grid 64 --mc 64 --batch 16 --dtype bf16 --steps 50 --warmup 5 --no-cpu-baseline --no-roofline > gpurun_out/cfg_c1e.log 2>&1; echo "c1 eager exit $?"; grep -o '"value": [0-9.]*, "unit": "steps/s"[^}]*"ms_per_step": [0-9.]*' gpurun_out/cfg_c1e.log | head -1
-timeout -k 10 300 python bench.py --mode sample --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > gpurun_out/cfg_c3g.log 2>&1; echo "c3 graph exit $?"; grep -o '"value": [0-9.]*, "unit": "steps/s"[^}]*"ms_per_step": [0-9.]*' gpurun_out/cfg_c3g.log | head -1; grep -o '"hip_graph": [a-z]*' gpurun_out/cfg_c3g.log
+timeout -k 10 400 python bench.py --mode sample --dims 3 --grid 128 --mc 32 --batch 2 --steps 3 --warmup 1 --no-cpu-baseline --dump-ops gpurun_out/ops_c5.txt > gpurun_out/cfg_c5.log 2>&1; echo "c5 exit $?"
+python - <<PY
+import json,re
+t=open("gpurun_out/cfg_c5.log").read()
+m=re.search(r'^\{.*\}$', t, re.M)
+j=json.loads(m.group(0)); print(j["value"], j["ms_per_step"], j["roofline"]["by_kind_ms"], j["roofline"]["achieved"])
+PY
+grep "attention" gpurun_out/ops_c5.txt | head -3
