@@ -160,8 +160,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
     local = local % max(1, torch.cuda.device_count())      # (only differs from LOCAL_RANK when ranks share a GPU in rehearsals)
-    if world > 1:
+    if world > 1 or os.environ.get("RHO_BENCH_FORCE_DIST") == "1":      # (the override rehearses the RCCL code path on one GPU)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         torch.cuda.set_device(local)
         # "nccl" IS RCCL on ROCm; RHO_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals
         dist.init_process_group(os.environ.get("RHO_DIST_BACKEND", "nccl"), rank=rank, world_size=world)

@@ -97,3 +97,48 @@ def test_dp_trainer_two_ranks_match_single_process():
     ref = torch.cat([p_.detach().reshape(-1) for p_ in ddpm.backbone.parameters()]).cpu()
     err = float((got[0] - ref).norm() / ref.norm())
     assert err < 2e-5, err     # fp32 summation order only (collective sum, wgrad atomics)
+
+
+def _rccl_single_rank(port, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), here, os.path.join(here, "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    from rho_diffusion_amd.parallel import GradBucketReducer
+    ps = [torch.nn.Parameter(torch.randn(1000 + 37 * i, device="cuda")) for i in range(6)]
+    arena = torch.randn(sum(p.numel() for p in ps), device="cuda")
+    off = 0
+    for p in ps:                                        # gradients as adjacent views of one arena (HipAdamW layout)
+        p.grad = arena[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    before = arena.clone()
+    red = GradBucketReducer(ps, bucket_bytes=8000)
+    assert red.avg_in_collective and len(red.buckets) >= 2
+    red.world = 2                                        # force the collective path on the 1-rank group (AVG over 1 rank = identity)
+    for p in reversed(ps):
+        red.on_ready([p])
+    red.finish()
+    t = torch.ones(5, device="cuda")
+    dist.broadcast(t, src=0)
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(arena, before)) and all(w is not None for w in [red])
+    q.put(("ok" if ok else "mismatch", int(sum(1 for b in red.buckets))))
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_bucketed_all_reduce_single_rank():
+    """The RCCL ("nccl") code path of the gradient reducer on the one GPU of the test box: communicator creation,
+    asynchronous ReduceOp.AVG all-reduce on flat arena views, wait, broadcast.  (Multi-rank numerics are covered by the
+    gloo tests; the 8-GPU run belongs to the driver.)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_single_rank, args=(_free_port(), q))
+    p.start()
+    status, nb = q.get(timeout=300)
+    p.join(120)
+    assert status == "ok" and nb >= 2 and p.exitcode == 0
