@@ -29,6 +29,7 @@ buffer addresses are stable.  PyTorch supplies memory and streams only.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
@@ -276,8 +277,7 @@ class _Plan:
         from ..models.unet_v2 import AttentionBlock, Downsample, ResBlock, Upsample
         self.eng = eng
         self.train = train
-        import os as _os
-        self.materialize_act = _os.environ.get("RHO_TRAIN_MATERIALIZE", "1") != "0"   # memory-for-time trade of training plans
+        self.materialize_act = os.environ.get("RHO_TRAIN_MATERIALIZE", "1") != "0"    # memory-for-time trade of training plans
         m = eng.model
         dt = eng.dtype
         dtc = hip.dtype_code(dt)
