@@ -559,6 +559,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
                 }
             }
             __syncthreads();
+            // (compile-time trip count: unrolled, so the residual loads of a thread's 2 - 4 rows are in flight together
+            // instead of one exposed global latency per row)
+#pragma unroll
             for (int it = tid; it < 128 * PPR; it += NTHR) {
                 const int lr = it / PPR, piece = it % PPR;
                 const int pp = tile_position((2 * pass + (lr >> 6)) * 2 + ((lr >> 5) & 1), lr & 31, p.TW, p.pair_lg);
