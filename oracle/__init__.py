@@ -12,8 +12,8 @@ the reference itself in the build container (``tests/golden/make_golden.py`` ->
 (``tests/pipeline/test_schedule.py:28-46``); see ``tests/test_oracle_golden.py``.
 
 Pinned: schedules, embeddings, UNetv2 modules / forward / gradients, DDPM loops, AdamW (g1-g8), the
-GaussianDiffusionPipeline sampling path (g9), ExponentialMovingAverage (g10).
-PARITY UNPINNED: the ``dds_*`` functions (diffusers-style DDPMScheduler of ``DiffusersDDPMPipeline``): that arithmetic
+GaussianDiffusionPipeline sampling path (g9) and training_step (g11), ExponentialMovingAverage (g10).
+PARITY UNPINNED: the ``dds_*`` functions (diffusers-style DDPMScheduler / training loss of ``DiffusersDDPMPipeline``): that arithmetic
 lives in the third-party ``diffusers`` package (unpinned in the reference's pyproject, not installed here); they restate
 the published scheduler and are checked for structure only.
 """

@@ -425,6 +425,28 @@ def gd_reverse_process(model, tab, x_init: Tensor, noise_tape: Sequence[Tensor],
     return {"buffer": buf, "denoised": x_t}
 
 
+def gd_training_loss(model, tab, data: Tensor, t: Tensor, noise: Tensor, y=None, predict_xstart: bool = True) -> Tensor:
+    """GaussianDiffusionPipeline.training_step (gaussian_diffusion.py:1153-1210): ``forward_process`` noises the data (:1014-1027)
+    and ``training_losses`` (:861-934) noises that result AGAIN with the same noise (:877) before the backbone sees it; with
+    the class defaults (predict_xstart, :218-219) the MSE target is the once-noised data (:922), otherwise the noise (:923);
+    ``mean_flat(...).mean()`` of equally sized samples = the plain mean."""
+    x_data = gd_q_sample(tab, data, t, noise)
+    x_t = gd_q_sample(tab, x_data, t, noise)
+    out = model(x_t, t, y)
+    target = x_data if predict_xstart else noise
+    return ((target - out) ** 2).mean()
+
+
+def dds_training_loss(model, sched, data: Tensor, t: Tensor, noise: Tensor, y=None, prediction_type: str = "epsilon") -> Tensor:
+    """DiffusersDDPMPipeline.training_step (diffusers.py:70-144; PARITY UNPINNED through ``dds_add_noise``): one ``add_noise``,
+    MSE against the noise (epsilon) or (sic, :121-122) against the NOISY images for prediction_type 'sample'.  The
+    ``clip_grad_norm_`` of :128 runs before ``backward`` on freshly zeroed gradients: no effect on the update."""
+    noisy = dds_add_noise(sched, data, noise, t)
+    out = model(noisy, t, y)
+    target = noise if prediction_type == "epsilon" else noisy
+    return ((out - target) ** 2).mean()
+
+
 def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, beta1=0.9, beta2=0.999,
                eps=1e-8, weight_decay=1e-2):
     """torch.optim.AdamW single-tensor update (abstract_diffusion.py:103-119 builds it with

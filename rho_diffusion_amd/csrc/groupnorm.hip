@@ -528,6 +528,21 @@ extern "C" int rho_gn_bwd_finalize(const float* partials, int64_t n, int64_t c, 
     return 0;
 }
 
+// Position blocks of the elementwise passes: `per` positions per workgroup, finer when that leaves the chip short of
+// workgroups (wide, small layers: C = 1024 at 4096 positions would be 128 workgroups), never below 4 positions per thread row.
+static int apply_nblk(int64_t s, int64_t per, int64_t C, int64_t n) {
+    int64_t nblk = (s + per - 1) / per;
+    const int64_t want = (2048 + n - 1) / n;
+    if (nblk < want) {
+        const int64_t ppi = 256 / (C >> 3) > 0 ? 256 / (C >> 3) : 1;
+        const int64_t cap = (s + 4 * ppi - 1) / (4 * ppi);
+        nblk = want < cap ? want : cap;
+    }
+    if (nblk < 1) nblk = 1;
+    if (nblk > 256) nblk = 256;
+    return (int)nblk;
+}
+
 template <typename T>
 __device__ __forceinline__ void store_octet(T* p, const float (&v)[8]);
 template <>
@@ -602,9 +617,7 @@ extern "C" int rho_gn_bwd_apply(const void* g, const void* x1, int64_t c1, const
     const int64_t C = c1 + c2;
     if (C % 32 != 0 || c1 % 8 != 0 || c2 % 8 != 0) return RHO_E_ALIGN;
     if (C > 2048) return RHO_E_SHAPE;
-    int nblk = (int)((s + 511) / 512);          // finer than the reducers: nothing to combine afterwards
-    if (nblk < 1) nblk = 1;
-    if (nblk > 256) nblk = 256;
+    const int nblk = apply_nblk(s, 512, C, n);  // finer than the reducers: nothing to combine afterwards
     dim3 grid((unsigned)nblk, (unsigned)n), block(256);
     if (dtype == RHO_BF16)
         hipLaunchKernelGGL(k_gn_bwd_apply<bf16_raw>, grid, block, 0, as_stream(stream), (const bf16_raw*)g, (const bf16_raw*)x1,
@@ -683,9 +696,7 @@ extern "C" int rho_gn_apply(const void* x1, int64_t c1, const void* x2, int64_t 
     const int64_t C = c1 + c2;
     if (C <= 0 || C % 8 != 0 || c1 % 8 != 0 || c2 % 8 != 0) return RHO_E_ALIGN;
     if (C > 2048 || n > 65535) return RHO_E_SHAPE;
-    int nblk = (int)((s + 1023) / 1024);
-    if (nblk < 1) nblk = 1;
-    if (nblk > 256) nblk = 256;
+    const int nblk = apply_nblk(s, 1024, C, n);
     dim3 grid((unsigned)nblk, (unsigned)n), block(256);
     if (dtype == RHO_BF16)
         hipLaunchKernelGGL(k_gn_apply<bf16_raw>, grid, block, 0, as_stream(stream), (const bf16_raw*)x1, (int)c1, (const bf16_raw*)x2,

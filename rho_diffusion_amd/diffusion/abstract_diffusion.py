@@ -114,6 +114,26 @@ class AbstractDiffusionPipeline(_Base):
             result[key] = self.reshape_timesteps(data, self.schedule[key].to(data.device)[t])
         return result
 
+    @staticmethod
+    def _parse_batch(batch):
+        """The batch forms every training_step of the reference accepts (ddpm.py:247-258): [data, labels] list,
+        {"data", "label"} dict, bare tensor."""
+        if isinstance(batch, list):
+            data, labels = batch
+        elif isinstance(batch, dict):
+            data, labels = batch.get("data"), batch.get("label")
+        else:
+            data, labels = batch, None
+        return data, labels
+
+    def _loss(self, pred: Tensor, target: Tensor) -> Tensor:
+        """``loss_func(pred, target)``; the default mean MSELoss runs as the HIP reduction + gradient (rho_mse)."""
+        loss_func = getattr(self, "loss_func", None)
+        if loss_func is None or (isinstance(loss_func, nn.MSELoss) and loss_func.reduction == "mean"):
+            from ..autograd import mse_loss
+            return mse_loss(pred, target)
+        return loss_func(pred, target)
+
     def _preembed_conditions(self, cc):
         """Sampling evaluates the backbone T times with the SAME labels: run the label embedding (``cond_fn``, e.g.
         MultiEmbeddings with its host-synchronising table lookup, conditioning.py:115-139) once and hand the UNet the

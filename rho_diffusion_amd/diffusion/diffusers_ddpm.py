@@ -7,8 +7,8 @@ arithmetic is restated from the published ``DDPMScheduler`` (PARITY UNPINNED, se
 options the reference sets: ``beta_schedule`` linear / squaredcos_cap_v2, ``rescale_betas_zero_snr``, ``prediction_type``
 epsilon / sample, ``variance_type`` fixed_small / fixed_large, ``clip_sample`` + ``clip_sample_range``.  ``DDPMScheduler``
 here offers that constructor, ``config``, ``timesteps``, ``add_noise`` and ``step``; both run in librho_hip.so
-(rho_q_sample_coef, rho_ddpm_sched_step).  ``training_step`` (epsilon MSE + the reference's in-place clip_grad_norm_) is
-not built: train with ``DDPM``.
+(rho_q_sample_coef, rho_ddpm_sched_step).  ``training_step`` is the epsilon-MSE objective of diffusers.py:70-144 on the
+same engine forward / backward as ``DDPM``.
 """
 from __future__ import annotations
 
@@ -202,5 +202,22 @@ class DiffusersDDPMPipeline(AbstractDiffusionPipeline):
         return {"buffer": buf, "denoised": x_t}
 
     def training_step(self, batch, batch_idx: int = 0):
-        raise NotImplementedError("DiffusersDDPMPipeline.training_step (diffusers.py:70-144) is outside the built path; "
-                                  "train with DDPM")
+        """diffusers.py:70-144: one ``add_noise``; MSE against the noise (``prediction_type`` epsilon) or, as the
+        reference writes it (:121-122), against the NOISY images for prediction_type 'sample'.  The reference's
+        ``clip_grad_norm_`` (:128) sits before ``backward`` and so acts on the freshly zeroed gradients of the step:
+        it has no effect on the update and is not reproduced."""
+        data, labels = self._parse_batch(batch)
+        self.data_shape = data.shape
+        self.data_dtype = data.dtype
+        t = self.random_timesteps(data.size(0)).to(data.device)
+        noisy_images, noise = self.forward_process(data, t)
+        noise_pred = self.backbone(noisy_images, t, labels) if labels is not None else self.backbone(noisy_images, t)
+        ptype = self.schedule.config.prediction_type
+        if ptype == "epsilon":
+            loss = self._loss(noise_pred, noise)
+        elif ptype == "sample":
+            loss = self._loss(noise_pred, noisy_images)
+        else:
+            raise Exception("Loss cannot be computed because the prediction type is not understood.")
+        self.log("train_loss", loss, prog_bar=True)
+        return loss

@@ -13,8 +13,8 @@ Arithmetic in librho_hip.so:
 The per-step scalars (four table entries) are kernel arguments computed on the host from the float64 tables exactly as
 ``_extract_into_tensor`` + the float32 tensor expressions of ``ddim_sample`` do; the loop never synchronises.
 
-Not built (SURVEY 8f note): this pipeline's ``training_step`` noises the data twice (:1186 then :877) and regresses the
-once-noised data; it is reproduced only in the oracle's documentation, not as a product path.
+``training_step`` (:1153-1210) reproduces the reference's objective as written: the data are noised twice with the same
+noise (:1186 then :877) and the backbone output is regressed on the once-noised data.
 """
 from __future__ import annotations
 
@@ -233,5 +233,21 @@ class GaussianDiffusionPipeline(AbstractDiffusionPipeline):
         save_model_checkpoint(self.backbone, "model.pth")
 
     def training_step(self, batch, batch_idx: int = 0):
-        raise NotImplementedError("GaussianDiffusionPipeline.training_step (double-noising, gaussian_diffusion.py:1153-1210) "
-                                  "is outside the built path; train with DDPM")
+        """:1153-1210 with ``training_losses`` (:861-934) for the class's fixed configuration (MSE loss, x0 prediction,
+        fixed variance): ``forward_process`` noises the data, ``training_losses`` noises that result AGAIN with the same
+        noise (:877) and regresses the backbone output on the once-noised data (START_X target, :922);
+        ``mean_flat(.).mean()`` over equally sized samples is the plain mean."""
+        data, labels = self._parse_batch(batch)
+        self.data_shape = data.shape
+        self.data_dtype = data.dtype
+        t = self.random_timesteps(data.size(0)).to(data.device)
+        x_data, noise = self.forward_process(data, t)
+        x_t = self.q_sample(x_data, t, noise=noise)
+        if labels is not None:
+            out = self.backbone(x_t, t, labels)
+        else:
+            out = self.backbone(x_t, t)
+        from ..autograd import mse_loss
+        loss = mse_loss(out, x_data)
+        self.log("train_loss", loss, prog_bar=True)
+        return loss

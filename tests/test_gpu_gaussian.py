@@ -167,3 +167,60 @@ def test_diffusers_style_pipeline_reverse_process_runs():
     assert torch.isfinite(res["denoised"]).all() and res["buffer"].shape[1] == 2
     xt, nz = pipe.forward_process(det_uniform(xshape, "dp_x0", -0.5, 0.5).to(DEV), torch.tensor([0, 19]))
     assert torch.isfinite(xt).all() and xt.shape == tuple(xshape) and float((xt[1] - nz[1]).abs().max()) < 1e-6   # abar[T-1] = 0
+
+
+G11_GRAD_KEYS = ("input_blocks.0.0.weight", "input_blocks.1.0.in_layers.2.weight", "time_embed.0.weight",
+                 "middle_block.0.emb_layers.1.weight", "out.2.weight", "out.2.bias")
+
+
+@pytest.mark.parametrize("case,T", [("tiny2d", 50), ("tiny3d", 20)])
+def test_gaussian_training_step_vs_reference_golden(case, T):
+    """GaussianDiffusionPipeline.training_step with injected (t, noise) against the loss and gradients recorded from the
+    reference class (g11: double noising, once-noised target); fp32 engine: loss 2e-4, gradients 2e-3 relative l2."""
+    g = load_golden("g11_gaussian_train.npz")
+    tag = f"{case}_T{T}"
+    pipe, xshape = _pipeline(case, T, "fp32")
+    pipe.train()
+    eps = det_normal(xshape, "gdtr_eps").to(DEV)
+    tq = torch.from_numpy(g[f"{tag}/t"])
+    pipe.noise = lambda data: eps
+    pipe.random_timesteps = lambda bs: tq
+    loss = pipe.training_step(det_uniform(xshape, "gdtr_x0", -1.0, 1.0).to(DEV))
+    assert abs(loss.item() - float(g[f"{tag}/loss"])) < 2e-4
+    loss.backward()
+    params = dict(pipe.backbone.named_parameters())
+    for k in G11_GRAD_KEYS:
+        assert rel_l2(params[k].grad.cpu(), torch.from_numpy(g[f"{tag}/grad/{k}"])) < 2e-3, k
+
+
+@pytest.mark.parametrize("pred", ["epsilon", "sample"])
+def test_diffusers_style_training_step_vs_oracle(pred):
+    """DiffusersDDPMPipeline.training_step (PARITY UNPINNED row: scheduler arithmetic restated) against the oracle's
+    dds_training_loss on the oracle UNet: loss and all parameter gradients (fp32 engine)."""
+    from rho_diffusion_amd.diffusion import DDPMScheduler, DiffusersDDPMPipeline
+    from rho_diffusion_amd.models import UNet
+    g4 = load_golden("g4_unet.npz")
+    case, T = "tiny2d", 40
+    kw, xshape, _ = UNET_CASES[case]
+    cfg, _, _, _ = case_inputs(case)
+    sch = DDPMScheduler(num_train_timesteps=T, beta_schedule="squaredcos_cap_v2", prediction_type=pred, variance_type="fixed_large",
+                        clip_sample=True, clip_sample_range=0.5, rescale_betas_zero_snr=True)
+    pipe = DiffusersDDPMPipeline(UNet, dict(kw, compute_dtype="fp32"), sch, nn.MSELoss, timesteps=T)
+    sd0 = det_state_dict(golden_template(g4, case), case)
+    pipe.backbone.load_state_dict(sd0)
+    pipe = pipe.to(DEV).train()
+    x0 = det_uniform(xshape, "ddtr_x0", -0.5, 0.5)
+    eps = det_normal(xshape, "ddtr_eps")
+    tq = torch.tensor([(11 * i + 5) % T for i in range(xshape[0])])
+    pipe.noise = lambda data: eps.to(DEV)
+    pipe.random_timesteps = lambda bs: tq
+    loss = pipe.training_step([x0.to(DEV), None] if pred == "sample" else {"data": x0.to(DEV)})
+    loss.backward()
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    ref = R.dds_training_loss(lambda x, t, y: R.unet_forward(sd, cfg, x, t), R.dds_tables(T, "squaredcos_cap_v2", True), x0, tq, eps,
+                              prediction_type=pred)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 2e-4
+    for name, p in pipe.backbone.named_parameters():
+        rg = sd[name].grad
+        assert rel_l2(p.grad.cpu(), rg) < 3e-3 or float((p.grad.cpu() - rg).abs().max()) < 1e-6, name

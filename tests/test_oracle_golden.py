@@ -182,6 +182,31 @@ def test_g9_gaussian_pipeline(case, T):
         assert rel_l2(res["buffer"], torch.from_numpy(g[f"{tag}/buffer"])) < 1e-4
 
 
+G11_GRAD_KEYS = ("input_blocks.0.0.weight", "input_blocks.1.0.in_layers.2.weight", "time_embed.0.weight",
+                 "middle_block.0.emb_layers.1.weight", "out.2.weight", "out.2.bias")
+
+
+@pytest.mark.parametrize("case,T", [("tiny2d", 50), ("tiny3d", 20)])
+def test_g11_gaussian_training_step(case, T):
+    """GaussianDiffusionPipeline.training_step recorded from the reference class (double noising, START_X target): loss and
+    six parameter gradients."""
+    g = load_golden("g11_gaussian_train.npz")
+    g4 = load_golden("g4_unet.npz")
+    tag = f"{case}_T{T}"
+    cfg, _, _, _ = case_inputs(case)
+    xshape = UNET_CASES[case][1]
+    sd = {k: v.requires_grad_(True) for k, v in det_state_dict(golden_template(g4, case), case).items()}
+    tab = R.gd_tables(R.gd_betas("cosine", T))
+    x0 = det_uniform(xshape, "gdtr_x0", -1.0, 1.0)
+    eps = det_normal(xshape, "gdtr_eps")
+    tq = torch.from_numpy(g[f"{tag}/t"])
+    loss = R.gd_training_loss(lambda x, t, y: R.unet_forward(sd, cfg, x, t), tab, x0, tq, eps)
+    assert abs(loss.item() - float(g[f"{tag}/loss"])) < 1e-5
+    loss.backward()
+    for k in G11_GRAD_KEYS:
+        assert rel_l2(sd[k].grad, torch.from_numpy(g[f"{tag}/grad/{k}"])) < 1e-4, k
+
+
 def test_g8_adamw():
     g = load_golden("g8_adamw.npz")
     p = det_normal((257,), "adam_p")
