@@ -51,6 +51,7 @@ struct ConvK {
     int tps;              // tiles per sample
     int lgTW, lgTH;       // tile extents are powers of two
     float inv_ihw, inv_iw;  // 1 / (IH*IW), 1 / IW: exact small-integer division through one float multiply
+    int cofast;           // cout tiles of one position tile on consecutive launch slots of one XCD
 };
 
 // floor(a / d) for 0 <= a < 2^20 with inv = 1.0f / d: (a + 0.5) * inv is at least 0.5 / d away from an integer, the
@@ -109,7 +110,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Give every XCD a contiguous range of
     // tiles instead of every 8th one, so that the halo faces shared by neighbouring tiles are re-read from the same L2.
     int bt = blockIdx.x;
-    {
+    int ct = blockIdx.y;
+    if (p.cofast) {
+        // several cout tiles and gridDim.x a multiple of 8: the cout tiles of one position tile take consecutive launch
+        // slots of the same XCD, so the input tile they all read comes from HBM once and from that L2 afterwards
+        const int L = blockIdx.x + gridDim.x * blockIdx.y;
+        const int slot = L >> 3;
+        ct = slot % (int)gridDim.y;
+        bt = (L & 7) * ((int)gridDim.x >> 3) + slot / (int)gridDim.y;
+    } else {
         const int nt = gridDim.x, per = nt >> 3;
         if (per > 0) {
             const int full = per << 3;                      // tiles covered by the 8 equal ranges; the tail keeps its index
@@ -119,7 +128,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
     const int tw_i = bt % p.tiles_w;
     const int th_i = (bt / p.tiles_w) % p.tiles_h;
     const int td_i = bt / (p.tiles_w * p.tiles_h);
-    const int co0 = blockIdx.y * BM;
+    const int co0 = ct * BM;
     const int n = blockIdx.z;
     const int od0 = td_i * p.TD, oh0 = th_i * p.TH, ow0 = tw_i * p.TW;
     const int gd_base = od0 - (KD / 2);
@@ -463,7 +472,33 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
             if (w_active) wx0[S_] = *reinterpret_cast<const uint4*>(ws);
             if constexpr (WROWS == 2) wx1[S_] = *reinterpret_cast<const uint4*>(ws + RPP * wrow_bytes);
         };
-        auto land = [&](auto SET, int ck) {                // registers -> LDS slot ck & 1 (prologue applied)
+        // The folded GroupNorm affine of the prologue: fetched from global memory inside the chunk loop it would be the
+        // youngest load in flight at every hand-over, and waiting for it (vmcnt is in-order) drains the whole register
+        // ring: one exposed memory latency per chunk (qkv projection: 0.8 ms at 260 TFLOP/s).  A tile that lies in one
+        // sample (block-uniform test) stages that sample's coefficients in LDS once; tiles straddling samples keep the
+        // global fetch.
+        float* const coef = reinterpret_cast<float*>(smem + 2 * HSLOT + 2 * BM * PITCH);   // [2][nck * CK]
+        const bool has_pre = p.pre_a != nullptr;
+        bool coef_lds = false;
+        if (has_pre) {
+            const int pos0 = ((n * p.D + gd_base) * p.Hs + gh_base) * p.Ws + gw_base;     // the tile's first position
+            const int smp_ref = (int)((long long)pos0 / p.S_in);
+            bool mine = !(p.up_h | p.up_w | p.zs_h | p.zs_w) && p.sh == 1 && p.sw == 1;
+#pragma unroll
+            for (int i = 0; i < XS; ++i)
+                if (spos[i] >= 0 && ssmp[i] != smp_ref) mine = false;
+            coef_lds = __syncthreads_and(mine ? 1 : 0) != 0;
+            if (coef_lds) {
+                const int cpad = nck * CK;
+                for (int i = tid; i < cpad; i += NTHR) {
+                    const bool in = i < p.cin;
+                    coef[i] = in ? p.pre_a[(size_t)smp_ref * p.cin + i] : 0.0f;
+                    coef[cpad + i] = in ? p.pre_b[(size_t)smp_ref * p.cin + i] : 0.0f;
+                }
+                __syncthreads();
+            }
+        }
+        auto land = [&](auto SET, int ck, auto LDSCOEF) {   // registers -> LDS slot ck & 1 (prologue applied)
             constexpr int S_ = decltype(SET)::value;
             const int c = ck * CK;
             char* const hs = smem + (ck & 1) * HSLOT;
@@ -471,10 +506,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
             for (int i = 0; i < XS; ++i) {
                 if (spos[i] != -2) {
                     uint4 u = spos[i] >= 0 ? xq[S_][i] : make_uint4(0u, 0u, 0u, 0u);
-                    if (p.pre_a != nullptr && spos[i] >= 0) {
-                        const int smp = (KD == 3) ? n : ssmp[(KD == 3) ? 0 : i];
-                        const size_t co = (size_t)smp * p.cin + c + piece * PE;
-                        u = apply_pre<T>(u, p.pre_a + co, p.pre_b + co, p.pre_silu);
+                    if (has_pre && spos[i] >= 0) {
+                        if constexpr (decltype(LDSCOEF)::value) {
+                            const float* const ca = coef + c + piece * PE;
+                            u = apply_pre<T>(u, ca, ca + nck * CK, p.pre_silu);
+                        } else {
+                            const size_t co = (size_t)ssmp[i] * p.cin + c + piece * PE;
+                            u = apply_pre<T>(u, p.pre_a + co, p.pre_b + co, p.pre_silu);
+                        }
                     }
                     const int hp = (tid >> 2) + RPP * i;
                     *reinterpret_cast<uint4*>(hs + hp * PITCH + piece * 16) = u;
@@ -506,20 +545,44 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
         using I2 = std::integral_constant<int, 2>;
         using I3 = std::integral_constant<int, 3>;
         issue(I0{}, 0); issue(I1{}, 1); issue(I2{}, 2); issue(I3{}, 3);
-#define RHO_ONE_STEP(K_, ISET)                                                                      \
+        // Groups of DX chunks run without a branch (same number of loads in flight on every path: the hand-over waits are
+        // counted, `vmcnt(9)`-style, instead of draining); the last nck % DX chunks have nothing left to fetch.
+#define RHO_ONE_STEP(K_, ISET, LC)                                                                  \
+        land(ISET{}, ck0 + K_, LC{});                                                               \
+        __syncthreads();                                                                            \
+        issue(ISET{}, ck0 + K_ + DX);                                                               \
+        compute(ck0 + K_);
+#define RHO_ONE_TAIL(K_, ISET, LC)                                                                  \
         if (ck0 + K_ < nck) {                                                                       \
-            land(ISET{}, ck0 + K_);                                                                 \
+            land(ISET{}, ck0 + K_, LC{});                                                           \
             __syncthreads();                                                                        \
-            issue(ISET{}, ck0 + K_ + DX);                                                           \
             compute(ck0 + K_);                                                                      \
         }
-        for (int ck0 = 0; ck0 < nck; ck0 += DX) {
-            RHO_ONE_STEP(0, I0)
-            RHO_ONE_STEP(1, I1)
-            RHO_ONE_STEP(2, I2)
-            RHO_ONE_STEP(3, I3)
+        if (!has_pre || coef_lds) {
+            int ck0 = 0;
+            for (; ck0 + DX <= nck; ck0 += DX) {
+                RHO_ONE_STEP(0, I0, std::true_type)
+                RHO_ONE_STEP(1, I1, std::true_type)
+                RHO_ONE_STEP(2, I2, std::true_type)
+                RHO_ONE_STEP(3, I3, std::true_type)
+            }
+            RHO_ONE_TAIL(0, I0, std::true_type)
+            RHO_ONE_TAIL(1, I1, std::true_type)
+            RHO_ONE_TAIL(2, I2, std::true_type)
+        } else {
+            int ck0 = 0;
+            for (; ck0 + DX <= nck; ck0 += DX) {
+                RHO_ONE_STEP(0, I0, std::false_type)
+                RHO_ONE_STEP(1, I1, std::false_type)
+                RHO_ONE_STEP(2, I2, std::false_type)
+                RHO_ONE_STEP(3, I3, std::false_type)
+            }
+            RHO_ONE_TAIL(0, I0, std::false_type)
+            RHO_ONE_TAIL(1, I1, std::false_type)
+            RHO_ONE_TAIL(2, I2, std::false_type)
         }
 #undef RHO_ONE_STEP
+#undef RHO_ONE_TAIL
     }
 #undef RHO_LOAD_W
 #undef RHO_STORE_W
@@ -863,6 +926,7 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
 
     const long long tiles = (long long)cdiv(k.Do, t.TD) * k.tiles_h * k.tiles_w;
     if (tiles > 0x7FFFFFFFLL || d.coutp / BM > 65535 || gridz > 65535) return RHO_E_SHAPE;
+    k.cofast = (d.coutp / BM > 1 && tiles % 8 == 0) ? 1 : 0;
     dim3 grid((unsigned)tiles, (unsigned)(d.coutp / BM), (unsigned)gridz);
     // fused output statistics: only where a tile belongs to one sample and the whole output is channels-last
     int64_t tps = 0;
@@ -877,7 +941,8 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
         k.stats = d.stats; k.tps = (int)tps;
     }
     size_t lds = (size_t)t.NP * PITCH + (size_t)WSLOTS * BM * PITCH;
-    if (taps == 1) lds = (size_t)2 * 256 * PITCH + (size_t)2 * BM * PITCH;      // 1x1x1: double-buffered activations + weights
+    if (taps == 1)        // 1x1x1: double-buffered activations + weights + the prologue coefficients of one sample
+        lds = (size_t)2 * 256 * PITCH + (size_t)2 * BM * PITCH + (d.pre_a ? (size_t)2 * k.cin * sizeof(float) : 0);
     if (d.stats) { const size_t lr = (size_t)(BM == 128 ? 512 : 256) * 16 * sizeof(float); if (lds < lr) lds = lr; }
     const size_t lds_epi = (size_t)128 * (BM * 4 + 16);       // epilogue transpose staging (fp32 rows, 128 positions per pass)
     if (d.split > 0 && lds < lds_epi) lds = lds_epi;
