@@ -18,6 +18,7 @@
 //   * Weights ([tap][cout][cin], prepared once) stream through a 2-deep LDS ring, one tap ahead.
 //
 // Replaces conv_nd at every call site of rho_diffusion/models/unet_v2.py (see include/rho_hip.h).
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_common.h"
@@ -66,11 +67,8 @@ __device__ __forceinline__ int fdiv_small(int a, float inv) { return (int)(((flo
 // each group gets either 16 consecutive positions of one row (TW >= 16) or, for 8-wide tiles, two rows whose halo
 // offset is 8 (mod 16) -- the row bit `pair_lg` chosen on the host.  (PMC before this map: SQ_LDS_BANK_CONFLICT was
 // 40-50 % of SQ_LDS_IDX_ACTIVE in this kernel.)
-__device__ __forceinline__ int tile_position(int m, int c, int TW, int pair_lg) {
-    const int q = c >> 2;
-    const int g = (0x96 >> q) & 1;                 // lane group of this column
-    const int k = ((q >> 1) << 2) | (c & 3);       // rank inside the group, 0..15
-    const int u = 2 * m + g;                       // 16-position unit, 0..15
+// position of rank k (0..15) of 16-position unit u (0..15): 16 positions whose halo rows are distinct mod 16
+__device__ __forceinline__ int unit_position(int u, int k, int TW, int pair_lg) {
     if (TW == 8 && pair_lg >= 0) {
         const int lo = u & ((1 << pair_lg) - 1);
         const int row = ((u >> pair_lg) << (pair_lg + 1)) | lo | ((k >> 3) << pair_lg);
@@ -78,12 +76,25 @@ __device__ __forceinline__ int tile_position(int m, int c, int TW, int pair_lg) 
     }
     return u * 16 + k;
 }
+__device__ __forceinline__ int tile_position(int m, int c, int TW, int pair_lg) {
+    const int q = c >> 2;
+    const int g = (0x96 >> q) & 1;                 // lane group of this column
+    const int k = ((q >> 1) << 2) | (c & 3);       // rank inside the group, 0..15
+    return unit_position(2 * m + g, k, TW, pair_lg);
+}
 
-// NW = 4: each wave owns 64 positions x all BM couts.  NW = 8 (BM = 128): waves form a 2 (cout halves) x 4 (position
-// quarters) grid, 64 couts x 64 positions each, so the workgroup keeps two waves on every SIMD (64 accumulator registers
-// per wave instead of 128) and one wave's LDS / barrier / vmcnt waits are covered by the other's MFMAs.
-// MAXP = halo slots per thread (halo positions <= MAXP * NW * 16).
-template <typename T, int KD, int KH, int KW, int BM, int MAXP, int NW>
+// The 16x16x32 MFMA layout (M16 variants): a lane holds row / column i = lane & 15 and the 16-byte K piece lane >> 4, so
+// a ds_read_b128 lane group {0-3, 12-15 | 20-27} mixes 8 rows at piece p with 8 rows at piece p + 1.  With the odd slot
+// pitch that is conflict-free iff both 8-row halves have distinct halo rows (mod 16) of ONE parity: column tile m16 takes
+// the ranks of parity (m16 & 1) of the two units of pair m16 >> 1 - half A (i in 0-3, 12-15) from the even unit, half B
+// (i in 4-11) from the odd one.  The same 32 positions as the 32-wide tile m16 >> 1 of the other layout.
+__device__ __forceinline__ int m16_hb(int i) { return (0x0FF0 >> i) & 1; }
+__device__ __forceinline__ int m16_k8(int i) { return m16_hb(i) ? i - 4 : (i < 4 ? i : i - 8); }
+__device__ __forceinline__ int tile_position16(int m16, int i, int TW, int pair_lg) {
+    return unit_position(2 * (m16 >> 1) + m16_hb(i), 2 * m16_k8(i) + (m16 & 1), TW, pair_lg);
+}
+
+template <typename T, int KD, int KH, int KW, int BM, int MAXP, int NW, bool M16 = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CK = ET<T>::CK;
@@ -169,14 +180,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
     }
 
     // ---- per-lane LDS byte offsets of the B (activation) fragments, per column tile and tap axis
+    // (M16: j = pair of 16-wide column tiles; the odd tile of a pair is one halo row = +PITCH further, stride 1 only)
     int offd[2], offh[2][KH], offw[2][KW];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int pp = tile_position(wpos * 2 + j, lane & 31, p.TW, p.pair_lg);
+        const int pp = M16 ? tile_position16(2 * (wpos * 2 + j), lane & 15, p.TW, p.pair_lg)
+                           : tile_position(wpos * 2 + j, lane & 31, p.TW, p.pair_lg);
         const int pw = pp & (p.TW - 1);
         const int ph = (pp >> p.lgTW) & (p.TH - 1);
         const int pd = pp >> (p.lgTW + p.lgTH);
-        offd[j] = pd * p.IH * p.IW * PITCH + 16 * half;
+        offd[j] = pd * p.IH * p.IW * PITCH + 16 * (M16 ? (lane >> 4) : half);
 #pragma unroll
         for (int kh = 0; kh < KH; ++kh) {
             const int ih = p.up_h ? (((ph + kh - 1) >> 1) + 1) : (ph * p.sh + kh);
@@ -188,7 +201,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
             offw[j][kw] = iw * PITCH;
         }
     }
-    const int a_off = (wco * (BM / WCO) + (lane & 31)) * PITCH + 16 * half;
+    // M16: MFMA row i of cout tile t (16 couts) lives in LDS row 32 * (t >> 1) + 16 * hb(i) + 2 * k8(i) + (t & 1)
+    const int a_off = M16 ? (wco * (BM / WCO) + 16 * m16_hb(lane & 15) + 2 * m16_k8(lane & 15)) * PITCH + 16 * (lane >> 4)
+                          : (wco * (BM / WCO) + (lane & 31)) * PITCH + 16 * half;
 
     f32x16_t acc[MT][2];
 #pragma unroll
@@ -206,7 +221,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
     const bool w_active = (BM >= RPP) || (tid < BM * 4);
     const char* const w_src0 = p.w + ((size_t)co0 + (tid >> 2)) * wrow_bytes + piece * 16;
     const size_t w_tap_stride = (size_t)p.coutp * wrow_bytes;
-    const int w_dst0 = (tid >> 2) * PITCH + piece * 16;
+    int w_row = tid >> 2;                  // LDS row of this thread's weight row(s); rows RPP apart keep the permutation
+    if constexpr (M16) w_row = (w_row & ~31) + 16 * m16_hb(w_row & 15) + 2 * m16_k8(w_row & 15) + ((w_row >> 4) & 1);
+    const int w_dst0 = w_row * PITCH + piece * 16;
     // Weights: G taps form one barrier step (G = 3 for the narrow-cout variants, where 8 MFMAs per barrier would be
     // barrier-bound), fetched PD steps ahead of their use (L2 latency ~1.5k cycles vs 0.25-0.5k cycles of MFMA per
     // tap) into a register ring of PD sets; set (step % PD) holds that step's G tiles; the LDS ring stays 2 deep.
@@ -350,7 +367,70 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
         }
         __syncthreads();
 
-        if constexpr (PIPE) {
+        if constexpr (PIPE && M16) {
+            // 16 MFMAs (16x16x32) per tap in four phases of 2 x 2 tiles: (a01,F) (a01,S) (a23,S) (a23,F), where F / S are the
+            // two column-tile pairs in an order that alternates with the tap.  Five 2-fragment register sets (a01, a23, bS and
+            // bF[2]); every set is read from LDS two phases (>= 128 MFMA cycles) before its first use:
+            //   phase 0 reads a23 (phase 2) | 1 reads the next tap's F | 2 reads the next tap's a01 | 3 reads the next tap's S.
+            static_assert(MT == 2 && NS % 2 == 1, "M16 tap schedule: 64 couts per wave, odd tap count");
+            typedef float f32x4_t __attribute__((ext_vector_type(4)));
+            uint4 a01[2], a23[2], bS[2], bF[2][2];
+            auto rdA = [&](int slot, int tp, uint4 (&fa)[2]) {
+                const char* w = wbuf + (size_t)slot * SLOT + a_off + tp * 32 * PITCH;
+                fa[0] = *reinterpret_cast<const uint4*>(w);
+                fa[1] = *reinterpret_cast<const uint4*>(w + PITCH);
+            };
+            auto rdB = [&](int tap, int jp, uint4 (&fb)[2]) {
+                const int kd = tap / (KH * KW), kh = (tap / KW) % KH, kw = tap % KW;
+                const char* b = halo + (kd * p.IH * p.IW * PITCH + offd[jp] + offh[jp][kh] + offw[jp][kw]);
+                fb[0] = *reinterpret_cast<const uint4*>(b);
+                fb[1] = *reinterpret_cast<const uint4*>(b + PITCH);
+            };
+            auto mm = [&](const uint4 (&fa)[2], const uint4 (&fb)[2], int tp, int jp) {   // tp, jp: compile-time after unrolling
+                f32x16_t& c = acc[tp][jp];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int q = 4 * (2 * tt + jj);
+                        f32x4_t v = {c[q], c[q + 1], c[q + 2], c[q + 3]};
+                        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[tt]), __builtin_bit_cast(bf16x8_t, fb[jj]),
+                                                                    v, 0, 0, 0);
+                        c[q] = v[0]; c[q + 1] = v[1]; c[q + 2] = v[2]; c[q + 3] = v[3];
+                    }
+            };
+            rdA(0, 0, a01);
+            rdB(0, 0, bF[0]);
+            rdB(0, 1, bS);
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                {
+                    const int nst = (st + LD) % NS;
+                    const int nckk = min(ck + (st + LD) / NS, nck - 1);
+                    RHO_LOAD_W((st + LD) % 3, nckk, nst);
+                }
+                if constexpr (HPF) {
+                    if (st == TPF) {
+                        __builtin_amdgcn_sched_barrier(0);     // keep the halo loads younger than the weight fetch above
+                        RHO_HALO_LOAD(min(ck + 1, nck - 1));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                const int slot = st % RS, nslot = (st + 1) % RS;
+                const bool more = st + 1 < NS;                 // next chunk's first tap: after its halo is staged
+                const int jf = st & 1, js = jf ^ 1;            // column-tile pair of F / S in this tap (swapped in the next)
+                rdA(slot, 1, a23);
+                mm(a01, bF[st & 1], 0, jf);
+                if (more) rdB(st + 1, js, bF[(st + 1) & 1]);
+                mm(a01, bS, 0, js);
+                if (more) rdA(nslot, 0, a01);
+                mm(a23, bS, 1, js);
+                if (more) rdB(st + 1, jf, bS);
+                mm(a23, bF[st & 1], 1, jf);
+                RHO_STORE_W((st + DS) % RS, (st + DS) % 3);
+                if (st % GB == GB - 1) __syncthreads();
+            }
+        } else if constexpr (PIPE) {
             // fragments: X = k-half 0 of the current step (already in flight), Y = k-half 1
             uint4 xa[MT], xb[2], ya[MT], yb[2];
             auto frag_reads = [&](int tap, int slot, int s_, uint4 (&fa)[MT], uint4 (&fb)[2]) {
@@ -610,12 +690,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
             if ((wpos >> 1) == pass) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int lr = (wpos & 1) * 64 + j * 32 + (lane & 31);
 #pragma unroll
                     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                         for (int rg = 0; rg < 4; ++rg) {
-                            const int cl = wco * (BM / WCO) + mi * 32 + rg * 8 + half * 4;
+                            // M16: group rg of acc[mi][j] = cout tile 2 * mi + (rg >> 1), column tile 2 * j + (rg & 1)
+                            const int lr = M16 ? (wpos & 1) * 64 + (2 * j + (rg & 1)) * 16 + (lane & 15) : (wpos & 1) * 64 + j * 32 + (lane & 31);
+                            const int cl = M16 ? wco * (BM / WCO) + 16 * (2 * mi + (rg >> 1)) + 4 * (lane >> 4)
+                                               : wco * (BM / WCO) + mi * 32 + rg * 8 + half * 4;
                             *reinterpret_cast<float4*>(stg + lr * ROWB + cl * 4) =
                                 make_float4(acc[mi][j][rg * 4 + 0], acc[mi][j][rg * 4 + 1], acc[mi][j][rg * 4 + 2], acc[mi][j][rg * 4 + 3]);
                         }
@@ -627,7 +709,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
 #pragma unroll
             for (int it = tid; it < 128 * PPR; it += NTHR) {
                 const int lr = it / PPR, piece = it % PPR;
-                const int pp = tile_position((2 * pass + (lr >> 6)) * 2 + ((lr >> 5) & 1), lr & 31, p.TW, p.pair_lg);
+                const int pp = M16 ? tile_position16((2 * pass + (lr >> 6)) * 4 + ((lr >> 4) & 3), lr & 15, p.TW, p.pair_lg)
+                                   : tile_position((2 * pass + (lr >> 6)) * 2 + ((lr >> 5) & 1), lr & 31, p.TW, p.pair_lg);
                 const int pw = pp & (p.TW - 1);
                 const int ph = (pp >> p.lgTW) & (p.TH - 1);
                 const int pd = pp >> (p.lgTW + p.lgTH);
@@ -706,8 +789,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
         return;
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int pp = tile_position(wpos * 2 + j, lane & 31, p.TW, p.pair_lg);
+    for (int jx = 0; jx < (M16 ? 4 : 2); ++jx) {
+        const int pp = M16 ? tile_position16(wpos * 4 + jx, lane & 15, p.TW, p.pair_lg) : tile_position(wpos * 2 + jx, lane & 31, p.TW, p.pair_lg);
         const int pw = pp & (p.TW - 1);
         const int ph = (pp >> p.lgTW) & (p.TH - 1);
         const int pd = pp >> (p.lgTW + p.lgTH);
@@ -716,11 +799,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
         const long long L = (((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
         const long long ns = L / p.S_out;
         const long long ps = L - ns * p.S_out;
+        const int j = M16 ? (jx >> 1) : jx;
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int co = co0 + wco * (BM / WCO) + mi * 32 + rg * 8 + half * 4;
+            for (int rx = 0; rx < (M16 ? 2 : 4); ++rx) {
+                const int rg = M16 ? 2 * rx + (jx & 1) : rx;
+                const int co = M16 ? co0 + wco * (BM / WCO) + 16 * (2 * mi + rx) + 4 * (lane >> 4)
+                                   : co0 + wco * (BM / WCO) + mi * 32 + rg * 8 + half * 4;
                 const float4 bv = *reinterpret_cast<const float4*>(p.bias + co);
                 float v0 = acc[mi][j][rg * 4 + 0] + bv.x;
                 float v1 = acc[mi][j][rg * 4 + 1] + bv.y;
@@ -788,9 +874,9 @@ namespace {
 
 using namespace rho_conv;
 
-template <typename T, int KD, int KH, int KW, int BM, int MAXP, int NW>
+template <typename T, int KD, int KH, int KW, int BM, int MAXP, int NW, bool M16 = false>
 int launch_one(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
-    auto fn = k_conv<T, KD, KH, KW, BM, MAXP, NW>;
+    auto fn = k_conv<T, KD, KH, KW, BM, MAXP, NW, M16>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -802,7 +888,14 @@ int launch_one(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
 
 // np = halo positions of the chosen tile.  BM = 128 runs 8 waves (slots per thread: 5 for np <= 640, else 14).
 template <typename T, int KD, int KH, int KW>
-int launch_bm(const ConvK& k, int BM, int np, dim3 grid, size_t lds, hipStream_t st) {
+int launch_bm(const ConvK& k, int BM, int np, dim3 grid, size_t lds, bool m16, hipStream_t st) {
+    if constexpr (sizeof(T) == 2 && KD * KH * KW > 1) {
+        // bf16, stride 1, no upsampling, regular halo: the 16x16x32 MFMA layout (holds a higher clock under load)
+        if (m16 && np <= 640) {
+            if (BM == 128) return launch_one<T, KD, KH, KW, 128, 5, 8, true>(k, grid, lds, st);
+            if (BM == 64) return launch_one<T, KD, KH, KW, 64, 10, 4, true>(k, grid, lds, st);
+        }
+    }
     if (BM == 128) {
         if (np <= 640) return launch_one<T, KD, KH, KW, 128, 5, 8>(k, grid, lds, st);
         return launch_one<T, KD, KH, KW, 128, 14, 8>(k, grid, lds, st);
@@ -819,11 +912,11 @@ int launch_bm(const ConvK& k, int BM, int np, dim3 grid, size_t lds, hipStream_t
 }
 
 template <typename T>
-int launch_taps(const rho_conv_desc& d, const ConvK& k, int BM, int np, dim3 grid, size_t lds, hipStream_t st) {
-    if (d.kd == 3 && d.kh == 3 && d.kw == 3) return launch_bm<T, 3, 3, 3>(k, BM, np, grid, lds, st);
-    if (d.kd == 1 && d.kh == 3 && d.kw == 3) return launch_bm<T, 1, 3, 3>(k, BM, np, grid, lds, st);
-    if (d.kd == 1 && d.kh == 1 && d.kw == 3) return launch_bm<T, 1, 1, 3>(k, BM, np, grid, lds, st);
-    if (d.kd == 1 && d.kh == 1 && d.kw == 1) return launch_bm<T, 1, 1, 1>(k, BM, np, grid, lds, st);
+int launch_taps(const rho_conv_desc& d, const ConvK& k, int BM, int np, dim3 grid, size_t lds, bool m16, hipStream_t st) {
+    if (d.kd == 3 && d.kh == 3 && d.kw == 3) return launch_bm<T, 3, 3, 3>(k, BM, np, grid, lds, m16, st);
+    if (d.kd == 1 && d.kh == 3 && d.kw == 3) return launch_bm<T, 1, 3, 3>(k, BM, np, grid, lds, m16, st);
+    if (d.kd == 1 && d.kh == 1 && d.kw == 3) return launch_bm<T, 1, 1, 3>(k, BM, np, grid, lds, m16, st);
+    if (d.kd == 1 && d.kh == 1 && d.kw == 1) return launch_bm<T, 1, 1, 1>(k, BM, np, grid, lds, m16, st);
     return RHO_E_ARG;
 }
 
@@ -947,8 +1040,10 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
     const size_t lds_epi = (size_t)128 * (BM * 4 + 16);       // epilogue transpose staging (fp32 rows, 128 positions per pass)
     if (d.split > 0 && lds < lds_epi) lds = lds_epi;
     hipStream_t st = as_stream(stream);
-    if (d.dtype == RHO_BF16) return launch_taps<bf16_raw>(d, k, BM, t.NP, grid, lds, st);
-    return launch_taps<float>(d, k, BM, t.NP, grid, lds, st);
+    static const bool m16_env = !(getenv("RHO_CONV_M16") && atoi(getenv("RHO_CONV_M16")) == 0);
+    const bool m16 = m16_env && d.dtype == RHO_BF16 && taps > 1 && d.sh == 1 && d.sw == 1 && !d.up_h && !d.up_w;
+    if (d.dtype == RHO_BF16) return launch_taps<bf16_raw>(d, k, BM, t.NP, grid, lds, m16, st);
+    return launch_taps<float>(d, k, BM, t.NP, grid, lds, false, st);
 }
 
 extern "C" int rho_conv_nd_fwd(const rho_conv_desc* dp, void* stream) { return conv_impl(dp, stream, nullptr); }

@@ -9,7 +9,7 @@ import torch
 from rho_diffusion_amd.engine import ops
 
 dev = "cuda"
-lib = C.CDLL(os.path.join(R0, "tools/probe/libconv_clk.so"))
+lib = C.CDLL(os.path.join(R0, "tools/probe", os.environ.get("RHO_CLK_LIB", "libconv_clk.so")))
 fn = lib.rho_conv_nd_fwd
 fn.argtypes = [C.c_void_p, C.c_void_p]; fn.restype = C.c_int
 lib.rho_dbg_set_buf.argtypes = [C.c_void_p]; lib.rho_dbg_set_buf.restype = C.c_int
