@@ -8,6 +8,9 @@ export TMPDIR=/tmp
 cd /tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --mode both --steps 5 --warmup 2 --train-steps 3 --no-cpu-baseline --no-roofline > $R/gpurun_out/rocprof_$TAG.log 2>&1
 echo "rocprof exit $?"
+# sampling leg alone: the 3x3x3 k_conv rows of this table are exactly the 52 launches per step that roofline.avg_launch_ms averages
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_sample -- python3 $R/bench.py --mode sample --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $R/gpurun_out/rocprof_${TAG}_sample.log 2>&1
+echo "rocprof (sample) exit $?"
 cd $R
 timeout -k 10 900 python bench.py --dump-ops gpurun_out/ops_$TAG.txt > gpurun_out/bench_$TAG.log 2>&1
 echo "bench exit $?"
