@@ -35,9 +35,9 @@ for name, (N, D, H, W, cin, cout) in cases.items():
             assert rc == 0, rc
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(200):
             fn(C.byref(d), st)
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 5
+        dt = (time.perf_counter() - t0) / 200
         row.append((int(lp.split("dbg")[-1][:-3]), dt * 1e3, fl / dt / 1e12))
     print(name, " | ".join(f"dbg{k}: {ms:.3f} ms ({tf:.0f} TF/s)" for k, ms, tf in row), flush=True)
