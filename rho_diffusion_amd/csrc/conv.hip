@@ -95,7 +95,9 @@ __device__ __forceinline__ int tile_position16(int m16, int i, int TW, int pair_
 }
 
 template <typename T, int KD, int KH, int KW, int BM, int MAXP, int NW, bool M16 = false>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p) {
+// (second launch bound = waves per SIMD the register allocation must allow: 2 for the 8-wave variants and for the 4-wave 1x1x1
+//  variant, which without it took 241 VGPRs + 64 AGPRs = one workgroup per CU and left its HBM-bound layers at 3.3 TB/s)
+__global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 10)) ? 2 : 1) void k_conv(const ConvK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CK = ET<T>::CK;
     constexpr int PE = ET<T>::PE;
@@ -530,7 +532,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
         // projection, 0.2 TFLOP).  Here chunk c + DX is fetched into a register ring while chunk c runs, activations and
         // weights are double-buffered in LDS, and one barrier per chunk orders both the hand-over and the slot reuse.
         constexpr int XS = (256 + RPP - 1) / RPP;          // activation rows per thread (the tile is 256 linear positions)
-        constexpr int DX = 4;                              // chunks in flight
+        constexpr int DX = (NW == 8) ? 4 : 2;              // chunks in flight (4-wave variants: two workgroups per CU share the registers)
         constexpr int HSLOT = 256 * PITCH;
         char* const wb2 = smem + 2 * HSLOT;                // [2][BM rows]
         uint4 xq[DX][XS], wx0[DX], wx1[DX];
@@ -624,7 +626,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
         using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>;
         using I3 = std::integral_constant<int, 3>;
-        issue(I0{}, 0); issue(I1{}, 1); issue(I2{}, 2); issue(I3{}, 3);
+        issue(I0{}, 0); issue(I1{}, 1);
+        if constexpr (DX == 4) { issue(I2{}, 2); issue(I3{}, 3); }
         // Groups of DX chunks run without a branch (same number of loads in flight on every path: the hand-over waits are
         // counted, `vmcnt(9)`-style, instead of draining); the last nck % DX chunks have nothing left to fetch.
 #define RHO_ONE_STEP(K_, ISET, LC)                                                                  \
@@ -643,23 +646,31 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_conv(const ConvK p
             for (; ck0 + DX <= nck; ck0 += DX) {
                 RHO_ONE_STEP(0, I0, std::true_type)
                 RHO_ONE_STEP(1, I1, std::true_type)
-                RHO_ONE_STEP(2, I2, std::true_type)
-                RHO_ONE_STEP(3, I3, std::true_type)
+                if constexpr (DX == 4) {
+                    RHO_ONE_STEP(2, I2, std::true_type)
+                    RHO_ONE_STEP(3, I3, std::true_type)
+                }
             }
             RHO_ONE_TAIL(0, I0, std::true_type)
-            RHO_ONE_TAIL(1, I1, std::true_type)
-            RHO_ONE_TAIL(2, I2, std::true_type)
+            if constexpr (DX == 4) {
+                RHO_ONE_TAIL(1, I1, std::true_type)
+                RHO_ONE_TAIL(2, I2, std::true_type)
+            }
         } else {
             int ck0 = 0;
             for (; ck0 + DX <= nck; ck0 += DX) {
                 RHO_ONE_STEP(0, I0, std::false_type)
                 RHO_ONE_STEP(1, I1, std::false_type)
-                RHO_ONE_STEP(2, I2, std::false_type)
-                RHO_ONE_STEP(3, I3, std::false_type)
+                if constexpr (DX == 4) {
+                    RHO_ONE_STEP(2, I2, std::false_type)
+                    RHO_ONE_STEP(3, I3, std::false_type)
+                }
             }
             RHO_ONE_TAIL(0, I0, std::false_type)
-            RHO_ONE_TAIL(1, I1, std::false_type)
-            RHO_ONE_TAIL(2, I2, std::false_type)
+            if constexpr (DX == 4) {
+                RHO_ONE_TAIL(1, I1, std::false_type)
+                RHO_ONE_TAIL(2, I2, std::false_type)
+            }
         }
 #undef RHO_ONE_STEP
 #undef RHO_ONE_TAIL

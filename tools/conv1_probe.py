@@ -13,7 +13,9 @@ N = 32
 cases = {"qkv 512->1536 T=4096": (1, 1, 4096, 512, 1536, 1024, True, False),
          "proj 512->512 T=4096": (1, 1, 4096, 512, 512, 512, False, True),
          "skip 1024->512 @64x8x8": (64, 8, 8, 1024, 512, 512, False, False),
-         "skip 192->64 @64^3": (64, 64, 64, 192, 64, 64, False, False)}
+         "skip 192->64 @64^3": (64, 64, 64, 192, 64, 64, False, False),
+         "skip 128->64 @64^3": (64, 64, 64, 128, 64, 64, False, False),
+         "dgrad-like 64->192 @64^3 (accumulating)": (64, 64, 64, 64, 192, 192, False, True)}
 libs = sorted(glob.glob(os.path.join(R0, "tools/probe/libconv_dbg*.so")), key=lambda p: int(p.split("dbg")[-1][:-3]))
 for name, (D, H, W, cin, cout, split, pre, res_) in cases.items():
     x = (torch.randn(N, D, H, W, cin, device=dev) * 0.5).to(torch.bfloat16)
