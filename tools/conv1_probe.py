@@ -11,6 +11,8 @@ dev = "cuda"
 N = 32
 # name: (D, H, W, cin, cout, split, pre, res)
 cases = {"qkv 512->1536 T=4096": (1, 1, 4096, 512, 1536, 1024, True, False),
+         "qkv-like, all channels-last": (1, 1, 4096, 512, 1536, 1536, True, False),
+         "qkv-like, no prologue": (1, 1, 4096, 512, 1536, 1024, False, False),
          "proj 512->512 T=4096": (1, 1, 4096, 512, 512, 512, False, True),
          "skip 1024->512 @64x8x8": (64, 8, 8, 1024, 512, 512, False, False),
          "skip 192->64 @64^3": (64, 64, 64, 192, 64, 64, False, False),
