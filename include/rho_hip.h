@@ -100,6 +100,18 @@ int rho_linear(const float* x, const float* w, const float* bias, const float* a
 /* [N, C, S] float32 (reference layout) -> channels-last [N, S, Cpad] dtype, channels >= C zeroed. */
 int rho_pack_input(const float* x, void* y, int dtype, int64_t n, int64_t c, int64_t s, int64_t cpad, void* stream);
 
+/* Stem convolution with Cin * taps <= Cpad (conv_nd(dims, in_channels = 1, mc, 3), unet_v2.py:535) as a 1x1x1 GEMM: the
+ * im2col operand  out[n][pos][ci * taps + tap] = x[n][ci][pos + offset(tap)]  (zero outside the volume and for k >= Cin * taps),
+ * channels-last bf16; taps are ordered (kd, kh, kw) as the rows of weight.reshape(Cout, Cin * taps). */
+int rho_im2col_taps(const float* x, void* out, int dtype, int64_t n, int64_t cin, int64_t d, int64_t h, int64_t w,
+                    int kd, int kh, int kw, int64_t cpad, void* stream);
+
+/* Head convolution with Cout = 1 (zero_module(conv_nd(dims, mc, out_channels = 1, 3)), unet_v2.py:679-683) as a 1x1x1 GEMM
+ * T[n][q][tap] = sum_c W[0][c][tap] * act[n][q][c] followed by  out[n][pos] = bias[0] + sum_tap T[n][pos + offset(tap)][tap]
+ * (fp32 sum in tap order, out-of-volume taps skipped = zero padding).  t: channels-last bf16 [N, D, H, W, Cpad]. */
+int rho_tap_gather_sum(const void* t, int dtype, int64_t n, int64_t d, int64_t h, int64_t w, int kd, int kh, int kw,
+                       int64_t cpad, const float* bias, float* out, void* stream);
+
 /* Conv weight [Cout, Cin, kd, kh, kw] float32 (PyTorch layout) -> [taps][CoutP][CinP] dtype,
  * zero padded.  Optional row permutation `row_src` (int32[CoutP], device; -1 = zero row) lets
  * the qkv projection be re-ordered (legacy vs new attention order, unet_v2.py:384,419-431). */

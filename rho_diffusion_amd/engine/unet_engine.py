@@ -54,6 +54,7 @@ class _ConvW:
             k.insert(0, 1)
         self.kernel = tuple(int(v) for v in k)
         self.taps = int(k[0] * k[1] * k[2])
+        self._geometry()
         ck = ops.elem_chunk(dtype)
         self.cinp = ((self.cin + ck - 1) // ck) * ck
         self.coutp = ((self.cout + 31) // 32) * 32
@@ -64,6 +65,16 @@ class _ConvW:
         self.wd: Optional[Tensor] = None     # dgrad weights, allocated with the first training plan
         self.zero_bias: Optional[Tensor] = None
         self.refresh()
+
+    def _geometry(self) -> None:          # subclasses re-interpret the parameter (see _StemAsGemm / _HeadAsGemm)
+        pass
+
+    def _source(self) -> Tensor:
+        w = self.weight.detach()
+        return w if w.is_contiguous() else w.contiguous()
+
+    def _bias_source(self) -> Tensor:
+        return self.bias_param.detach()
 
     def enable_dgrad(self) -> None:
         if self.wd is None:
@@ -80,16 +91,53 @@ class _ConvW:
               "rho_prep_conv_weight_dgrad")
 
     def refresh(self) -> None:
-        w = self.weight.detach()
-        if not w.is_contiguous():
-            w = w.contiguous()
-        ops.prep_conv_weight(w, self.dtype, self.coutp, self.cinp, self.row_src, out=self.w)
-        b = self.bias_param.detach()
+        ops.prep_conv_weight(self._source(), self.dtype, self.coutp, self.cinp, self.row_src, out=self.w)
+        b = self._bias_source()
         if self.row_src is not None:
             b = b[self.row_src.long()]           # gather (data movement only)
         self.b[: b.numel()].copy_(b)
         if self.wd is not None:
             self._refresh_dgrad()
+
+
+class _StemAsGemm(_ConvW):
+    """Stem conv with cin * taps <= 32 viewed as a 1x1x1 conv over the im2col operand (rho_im2col_taps): weight
+    [cout, cin * taps] in the (ci, kd, kh, kw) order of ``weight.reshape``."""
+
+    def __init__(self, weight: nn.Parameter, bias: nn.Parameter, dtype):
+        self.taps3 = int(weight[0, 0].numel())
+        self.kernel3 = tuple([1] * (3 - (weight.dim() - 2)) + [int(v) for v in weight.shape[2:]])
+        super().__init__(weight, bias, dtype)
+
+    def _geometry(self):
+        self.kernel, self.taps = (1, 1, 1), 1
+        self.cin = self.weight.shape[1] * self.taps3
+
+    def _source(self) -> Tensor:
+        return self.weight.detach().reshape(self.cout, self.cin, 1, 1, 1).contiguous()
+
+
+class _HeadAsGemm(_ConvW):
+    """Head conv with cout == 1 viewed as a 1x1x1 conv cin -> taps (rows = taps, padded to 32 output channels) whose
+    result rho_tap_gather_sum folds over the taps; the bias is added there."""
+
+    def __init__(self, weight: nn.Parameter, bias: nn.Parameter, dtype):
+        self.taps3 = int(weight[0, 0].numel())
+        self.kernel3 = tuple([1] * (3 - (weight.dim() - 2)) + [int(v) for v in weight.shape[2:]])
+        super().__init__(weight, bias, dtype)
+
+    def _geometry(self):
+        self.kernel, self.taps = (1, 1, 1), 1
+        self.cout = 32
+
+    def _source(self) -> Tensor:
+        w = self.weight.detach()[0].reshape(self.cin, self.taps3).t()          # [taps, cin]
+        full = torch.zeros(32, self.cin, 1, 1, 1, dtype=w.dtype, device=w.device)
+        full[: self.taps3, :, 0, 0, 0] = w
+        return full
+
+    def _bias_source(self) -> Tensor:
+        return torch.zeros(32, dtype=torch.float32, device=self.weight.device)
 
 
 class _Pool:
@@ -142,6 +190,15 @@ class UNetEngine:
         key = id(mod)
         if key not in self._conv_of:
             cw = _ConvW(mod.weight, mod.bias, self.dtype, row_src)
+            self._conv_of[key] = cw
+            self._convs.append(cw)
+        return self._conv_of[key]
+
+    def _conv_as_gemm(self, mod: nn.Module, cls) -> _ConvW:
+        """The stem / head convolution re-read as a 1x1x1 GEMM (inference plans of the bf16 engine)."""
+        key = (id(mod), cls.__name__)
+        if key not in self._conv_of:
+            cw = cls(mod.weight, mod.bias, self.dtype)
             self._conv_of[key] = cw
             self._convs.append(cw)
         return self._conv_of[key]
@@ -369,7 +426,7 @@ class _Plan:
             return dict(x1=x1, x2=x2, norm=norm, film_off=off, a=a, b=b, st=st, part=part, N=N, S=S, C=Cc, nblk=nblk)
 
         def conv(x1, x2, cw, *, stride_hw=(1, 1), up_hw=(0, 0), pre=None, pre_silu=False, res=None, res_add_off=None,
-                 split=None, y2_dtype=None, stem=False):
+                 split=None, y2_dtype=None, stem=False, want_stats=True):
             cout = cw.cout
             split_ = cout if split is None else split
             N, Do, Ho, Wo = ops.conv_out_shape(x1.shape, cw.kernel, stride_hw, up_hw)
@@ -398,7 +455,7 @@ class _Plan:
             if res_add_off is not None:
                 d.res_add = self.film.data_ptr() + 4 * res_add_off
                 d.res_add_stride = self.film.shape[1]
-            if y is not None and split_ == cout:
+            if y is not None and split_ == cout and want_stats:
                 # GroupNorm statistics of the output ride along in the epilogue where the geometry allows it
                 tiles = int(L.rho_conv_stats_tiles(C.byref(d)))
                 if tiles > 0:
@@ -458,15 +515,24 @@ class _Plan:
                     up = (1, 1) if dims >= 2 else (0, 1)
                     h1, _ = conv(h1, None, eng._conv(layer.conv), up_hw=up)
                 else:  # the stem conv
-                    h1, _ = conv(h1, None, eng._conv(layer), stem=True)
+                    h1, _ = conv(h1, None, stem, stem=True)
             return h1
 
         # ---- the network
+        # Inference plans of the bf16 engine run a 1-channel stem / head as 1x1x1 GEMMs (see rho_im2col_taps /
+        # rho_tap_gather_sum: the 3x3x3 form pads the single channel to 32 and spends 31/32 of its matrix work on zeros).
+        gemm_ends = (not train) and dt == torch.bfloat16 and os.environ.get("RHO_GEMM_ENDS", "1") != "0"
         stem = eng._conv(m.input_blocks[0][0])
         self.x_in = buf(*xshape, dtype=torch.float32)
-        self.x_cl = buf(B, D, H, W, stem.cinp)
-        pk = (ptr(self.x_in), ptr(self.x_cl), dtc, B, xshape[1], D * H * W, stem.cinp)
-        self.ops.append(lambda s, a=pk: L.rho_pack_input(*a, s))
+        if gemm_ends and stem.taps > 1 and stem.cin * stem.taps <= 32:
+            stem = eng._conv_as_gemm(m.input_blocks[0][0], _StemAsGemm)
+            self.x_cl = buf(B, D, H, W, stem.cinp)
+            pk = (ptr(self.x_in), ptr(self.x_cl), dtc, B, xshape[1], D, H, W) + stem.kernel3 + (stem.cinp,)
+            self.ops.append(lambda s, a=pk: L.rho_im2col_taps(*a, s))
+        else:
+            self.x_cl = buf(B, D, H, W, stem.cinp)
+            pk = (ptr(self.x_in), ptr(self.x_cl), dtc, B, xshape[1], D * H * W, stem.cinp)
+            self.ops.append(lambda s, a=pk: L.rho_pack_input(*a, s))
         self.info.append(dict(kind="pack", flops=0.0, bytes=4.0 * B * xshape[1] * D * H * W + 2.0 * B * D * H * W * stem.cinp))
 
         hs = []
@@ -478,7 +544,16 @@ class _Plan:
         for blk in m.output_blocks:
             h = run_block(blk, h, hs.pop())
         g = gn(h, None, m.out[0])
-        _, y2 = conv(h, None, eng._conv(m.out[2]), pre=g, pre_silu=True, split=0, y2_dtype=torch.float32)
+        head = eng._conv(m.out[2])
+        if gemm_ends and head.taps > 1 and head.cout == 1:
+            hg = eng._conv_as_gemm(m.out[2], _HeadAsGemm)
+            tt, _ = conv(h, None, hg, pre=g, pre_silu=True, want_stats=False)          # [B, D, H, W, 32]: one column per tap
+            y2 = buf(B, 1, D * H * W, dtype=torch.float32)
+            ga = (ptr(tt), dtc, B, D, H, W) + hg.kernel3 + (hg.coutp, ptr(m.out[2].bias), ptr(y2))
+            self.ops.append(lambda s, a=ga: L.rho_tap_gather_sum(*a, s))
+            self.info.append(dict(kind="tap_sum", flops=0.0, bytes=2.0 * tt.numel() + 4.0 * y2.numel()))
+        else:
+            _, y2 = conv(h, None, head, pre=g, pre_silu=True, split=0, y2_dtype=torch.float32)
         self.out = y2.view(B, m.out_channels, *xshape[2:])
 
         self.bwd: List[Callable[[int], int]] = []

@@ -57,6 +57,9 @@ SIGNATURES = {
     "rho_conv_stats_tiles": (c_int64, [C.POINTER(ConvDesc)]),
     "rho_gn_finalize2": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rho_im2col_taps": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int64, c_void_p]),
+    "rho_tap_gather_sum": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int64, c_void_p, c_void_p,
+                                   c_void_p]),
     "rho_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     # ---- backward
     "rho_conv_nd_wgrad": (c_int, [C.POINTER(ConvDesc), c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),

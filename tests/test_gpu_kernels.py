@@ -358,3 +358,48 @@ def test_conv_fused_groupnorm_statistics(ops, dtype, kind):
         hip.check(L.rho_gn_finalize2(ops.ptr(sbuf), 1, tiles, cout, ops.ptr(p2), 0, nb2, c2, N, S, ops.ptr(gamma), ops.ptr(beta),
                                      None, None, 0, None, ops.ptr(a2), ops.ptr(b2), ops.stream()), "gn_finalize2")
         assert rel_l2(a2.cpu(), a_ref.cpu()) < 1e-5 and rel_l2(b2.cpu(), b_ref.cpu()) < 1e-4
+
+
+def test_im2col_taps_and_tap_gather_sum(ops):
+    """The two helpers that let a 1-channel stem / head convolution run as a 1x1x1 GEMM (rho_im2col_taps,
+    rho_tap_gather_sum): im2col columns exact (bf16 rounding of the gathered values), gather = fp32 sum in tap order."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from rho_diffusion_amd import hip
+    L = hip.lib()
+    torch.manual_seed(5)
+    for (N, cin, D, H, W, k) in [(2, 1, 5, 6, 7, (3, 3, 3)), (3, 2, 1, 9, 10, (1, 3, 3)), (2, 1, 1, 1, 33, (1, 1, 3))]:
+        taps = k[0] * k[1] * k[2]
+        x = torch.randn(N, cin, D, H, W)
+        out = torch.empty(N, D, H, W, 32, dtype=torch.bfloat16, device=DEV)
+        xd = x.to(DEV)
+        rc = L.rho_im2col_taps(xd.data_ptr(), out.data_ptr(), 1, N, cin, D, H, W, k[0], k[1], k[2], 32, hip.stream())
+        assert rc == 0
+        xp = F.pad(x, (k[2] // 2, k[2] // 2, k[1] // 2, k[1] // 2, k[0] // 2, k[0] // 2))
+        cols = []
+        for ci in range(cin):
+            for a in range(k[0]):
+                for b in range(k[1]):
+                    for c in range(k[2]):
+                        cols.append(xp[:, ci, a:a + D, b:b + H, c:c + W])
+        ref = torch.stack(cols, dim=-1).to(torch.bfloat16)
+        got = out.cpu()
+        assert torch.equal(got[..., : cin * taps], ref)
+        assert float(got[..., cin * taps:].abs().max()) == 0.0
+        # gather-sum: T[q][tap] -> out[pos] = bias + sum_tap T[pos + off(tap)][tap]
+        t = torch.randn(N, D, H, W, 32).to(torch.bfloat16)
+        bias = torch.tensor([0.37])
+        o = torch.empty(N, 1, D * H * W, device=DEV)
+        td, bd = t.to(DEV), bias.to(DEV)
+        rc = L.rho_tap_gather_sum(td.data_ptr(), 1, N, D, H, W, k[0], k[1], k[2], 32, bd.data_ptr(), o.data_ptr(), hip.stream())
+        assert rc == 0
+        tp = F.pad(t.float().permute(0, 4, 1, 2, 3), (k[2] // 2, k[2] // 2, k[1] // 2, k[1] // 2, k[0] // 2, k[0] // 2))
+        acc = torch.full((N, D, H, W), 0.37)
+        tap = 0
+        for a in range(k[0]):
+            for b in range(k[1]):
+                for c in range(k[2]):
+                    acc = acc + tp[:, tap, a:a + D, b:b + H, c:c + W]
+                    tap += 1
+        assert torch.allclose(o.cpu().view(N, D, H, W), acc, rtol=1e-6, atol=1e-6)
+    assert L.rho_im2col_taps(xd.data_ptr(), out.data_ptr(), 0, 1, 1, 1, 1, 8, 1, 1, 3, 32, hip.stream()) != 0      # bf16 only

@@ -201,3 +201,24 @@ def test_reverse_process_hip_graph_matches_eager_loop():
     assert torch.equal(outs[True][1], outs[False][1])
     assert outs[True][2] == outs[False][2]
     assert torch.isfinite(outs[True][0]).all()
+
+
+def test_stem_and_head_as_gemm_match_the_conv_form(monkeypatch):
+    """bf16 inference plans run the 1-channel stem / head convolutions as 1x1x1 GEMMs (RHO_GEMM_ENDS, default on): same
+    prediction as the 3x3(x3) form within bf16 noise (the head's per-tap partial sums are rounded to bf16 once)."""
+    from rho_diffusion_amd.models import UNet
+    g4 = load_golden("g4_unet.npz")
+    for case in ("tiny3d", "tiny2d"):
+        kw, xshape, _ = UNET_CASES[case]
+        sd = det_state_dict(golden_template(g4, case), case)
+        cfg, x, t, y = case_inputs(case)
+        outs = []
+        for flag in ("1", "0"):
+            monkeypatch.setenv("RHO_GEMM_ENDS", flag)
+            m = UNet(**dict(kw, compute_dtype="bf16"))
+            m.load_state_dict(sd)
+            m = m.to(DEV).eval()
+            with torch.no_grad():
+                outs.append(m(x.to(DEV), t.to(DEV)).float().cpu())
+        assert rel_l2(outs[0], outs[1]) < 1e-2, case
+        assert rel_l2(outs[0], torch.from_numpy(g4[f"{case}/pred"])) < 3e-2, case
