@@ -138,7 +138,7 @@ def roofline_of(plan, args):
     if os.path.exists(tpath) and args.dtype == "bf16" and args.batch == 32 and args.grid == 64 and args.dims == 3 and args.mc == 64:
         with open(tpath) as f:
             tj = json.load(f)
-        traffic, traffic_note = tj["hbm_bytes_per_launch"], "profiles/r01g_pmc_traffic_conv3.json (PMC FETCH_SIZE x2 + WRITE_SIZE, average per launch of the same 52 launches)"
+        traffic, traffic_note = tj["hbm_bytes_per_launch"], "profiles/r01g_pmc_traffic_conv3.json (PMC FETCH_SIZE x2 + WRITE_SIZE, average per launch of the same conv3 launches)"
     alg_bytes = sum(p["bytes"] for p in conv3)
     return {
         "bound": "mfma", "kernel": "k_conv (3x3x3 implicit GEMM, LDS halo tile)", "achieved": achieved, "peak": peak,
