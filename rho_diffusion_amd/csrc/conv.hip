@@ -695,10 +695,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
         float ssum[PE], ssq[PE];                          // GroupNorm partial sums of this thread's channel piece
 #pragma unroll
         for (int e = 0; e < PE; ++e) ssum[e] = ssq[e] = 0.0f;
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            __syncthreads();                              // tap loop / previous pass done with the LDS bytes reused here
-            if ((wpos >> 1) == pass) {
+        {
+            __syncthreads();                              // tap loop done with the LDS bytes reused here
+            {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -706,7 +705,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
 #pragma unroll
                         for (int rg = 0; rg < 4; ++rg) {
                             // M16: group rg of acc[mi][j] = cout tile 2 * mi + (rg >> 1), column tile 2 * j + (rg & 1)
-                            const int lr = M16 ? (wpos & 1) * 64 + (2 * j + (rg & 1)) * 16 + (lane & 15) : (wpos & 1) * 64 + j * 32 + (lane & 31);
+                            const int lr = M16 ? wpos * 64 + (2 * j + (rg & 1)) * 16 + (lane & 15) : wpos * 64 + j * 32 + (lane & 31);
                             const int cl = M16 ? wco * (BM / WCO) + 16 * (2 * mi + (rg >> 1)) + 4 * (lane >> 4)
                                                : wco * (BM / WCO) + mi * 32 + rg * 8 + half * 4;
                             *reinterpret_cast<float4*>(stg + lr * ROWB + cl * 4) =
@@ -714,20 +713,38 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                         }
                 }
             }
-            __syncthreads();
-            // (compile-time trip count: unrolled, so the residual loads of a thread's 2 - 4 rows are in flight together
-            // instead of one exposed global latency per row)
+            // Item k of this thread: row tid / PPR + k * (NTHR / PPR), 16-byte channel piece tid % PPR.  Output offsets and
+            // the residual loads are issued BEFORE the barrier that publishes the staged rows: their latency runs under the
+            // barrier and the LDS reads instead of after them (one exposed global latency per tile otherwise).
+            constexpr int NIT = 256 * PPR / NTHR;
+            static_assert(256 * PPR % NTHR == 0, "whole items per thread");
+            long long eoff[NIT];
+            uint4 rres[NIT];
+            {
+                const int piece = tid % PPR;
 #pragma unroll
-            for (int it = tid; it < 128 * PPR; it += NTHR) {
-                const int lr = it / PPR, piece = it % PPR;
-                const int pp = M16 ? tile_position16((2 * pass + (lr >> 6)) * 4 + ((lr >> 4) & 3), lr & 15, p.TW, p.pair_lg)
-                                   : tile_position((2 * pass + (lr >> 6)) * 2 + ((lr >> 5) & 1), lr & 31, p.TW, p.pair_lg);
-                const int pw = pp & (p.TW - 1);
-                const int ph = (pp >> p.lgTW) & (p.TH - 1);
-                const int pd = pp >> (p.lgTW + p.lgTH);
-                const int od = od0 + pd, oh = oh0 + ph, ow = ow0 + pw;
-                if (od >= p.Do || oh >= p.Ho || ow >= p.Wo) continue;
-                const long long L = (((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
+                for (int k = 0; k < NIT; ++k) {
+                    const int lr = tid / PPR + k * (NTHR / PPR);
+                    const int pp = M16 ? tile_position16((lr >> 6) * 4 + ((lr >> 4) & 3), lr & 15, p.TW, p.pair_lg)
+                                       : tile_position((lr >> 6) * 2 + ((lr >> 5) & 1), lr & 31, p.TW, p.pair_lg);
+                    const int pw = pp & (p.TW - 1);
+                    const int ph = (pp >> p.lgTW) & (p.TH - 1);
+                    const int pd = pp >> (p.lgTW + p.lgTH);
+                    const int od = od0 + pd, oh = oh0 + ph, ow = ow0 + pw;
+                    const bool ok = od < p.Do && oh < p.Ho && ow < p.Wo;
+                    const long long L = (((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
+                    eoff[k] = ok ? L : -1;
+                    rres[k] = make_uint4(0u, 0u, 0u, 0u);
+                    if (ok && p.res != nullptr)
+                        rres[k] = *reinterpret_cast<const uint4*>(p.res + ((size_t)L * p.split + co0 + piece * PE) * sizeof(T));
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                if (eoff[k] < 0) continue;
+                const int lr = tid / PPR + k * (NTHR / PPR), piece = tid % PPR;
+                const long long L = eoff[k];
                 const int co = co0 + piece * PE;
                 float v[PE];
 #pragma unroll
@@ -747,7 +764,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                 const size_t eo = (size_t)L * p.split + co;
                 if constexpr (sizeof(T) == 2) {
                     if (p.res != nullptr) {
-                        const uint4 r = *reinterpret_cast<const uint4*>(p.res + eo * 2);
+                        const uint4 r = rres[k];
                         v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xFFFF0000u);
                         v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xFFFF0000u);
                         v[4] += __uint_as_float(r.z << 16); v[5] += __uint_as_float(r.z & 0xFFFF0000u);
@@ -763,8 +780,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                     }
                 } else {
                     if (p.res != nullptr) {
-                        const float4 r = *reinterpret_cast<const float4*>(p.res + eo * 4);
-                        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+                        const uint4 r = rres[k];
+                        v[0] += __uint_as_float(r.x); v[1] += __uint_as_float(r.y); v[2] += __uint_as_float(r.z); v[3] += __uint_as_float(r.w);
                     }
                     *reinterpret_cast<float4*>(p.y + eo * 4) = make_float4(v[0], v[1], v[2], v[3]);
                 }
@@ -1048,7 +1065,7 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
     if (taps == 1)        // 1x1x1: double-buffered activations + weights + the prologue coefficients of one sample
         lds = (size_t)2 * 256 * PITCH + (size_t)2 * BM * PITCH + (d.pre_a ? (size_t)2 * k.cin * sizeof(float) : 0);
     if (d.stats) { const size_t lr = (size_t)(BM == 128 ? 512 : 256) * 16 * sizeof(float); if (lds < lr) lds = lr; }
-    const size_t lds_epi = (size_t)128 * (BM * 4 + 16);       // epilogue transpose staging (fp32 rows, 128 positions per pass)
+    const size_t lds_epi = (size_t)256 * (BM * 4 + 16);       // epilogue transpose staging (fp32 rows, all 256 positions at once)
     if (d.split > 0 && lds < lds_epi) lds = lds_epi;
     hipStream_t st = as_stream(stream);
     static const bool m16_env = !(getenv("RHO_CONV_M16") && atoi(getenv("RHO_CONV_M16")) == 0);

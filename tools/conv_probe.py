@@ -22,7 +22,9 @@ for name, (N, D, H, W, cin, cout) in cases.items():
     a = torch.ones(N, cin, device=dev); bb = torch.zeros(N, cin, device=dev)
     res = torch.zeros(N, D, H, W, cout, device=dev, dtype=torch.bfloat16)
     y = torch.empty(N, D, H, W, cout, device=dev, dtype=torch.bfloat16)
-    d = ops.make_conv_desc(x, None, w, b, kernel=(3, 3, 3), cout=cout, split=cout, y=y, y2=None, pre_a=a, pre_b=bb, pre_silu=True, res=res)
+    use_res = os.environ.get("RHO_PROBE_RES", "1") != "0"
+    d = ops.make_conv_desc(x, None, w, b, kernel=(3, 3, 3), cout=cout, split=cout, y=y, y2=None, pre_a=a, pre_b=bb, pre_silu=True,
+                           res=res if use_res else None)
     fl = 2.0 * N * D * H * W * cin * cout * 27
     row = []
     for lp in libs:
