@@ -720,8 +720,20 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
             static_assert(256 * PPR % NTHR == 0, "whole items per thread");
             long long eoff[NIT];
             uint4 rres[NIT];
+            float bia[PE];                                  // bias (+ the per-sample additive term, 3-D: one sample per tile)
             {
                 const int piece = tid % PPR;
+#pragma unroll
+                for (int q4 = 0; q4 < PE / 4; ++q4) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(p.bias + co0 + piece * PE + q4 * 4);
+                    bia[q4 * 4 + 0] = b4.x; bia[q4 * 4 + 1] = b4.y; bia[q4 * 4 + 2] = b4.z; bia[q4 * 4 + 3] = b4.w;
+                    if constexpr (KD == 3) {
+                        if (p.res_add != nullptr) {
+                            const float4 e = *reinterpret_cast<const float4*>(p.res_add + (long long)n * p.res_add_stride + co0 + piece * PE + q4 * 4);
+                            bia[q4 * 4 + 0] += e.x; bia[q4 * 4 + 1] += e.y; bia[q4 * 4 + 2] += e.z; bia[q4 * 4 + 3] += e.w;
+                        }
+                    }
+                }
 #pragma unroll
                 for (int k = 0; k < NIT; ++k) {
                     const int lr = tid / PPR + k * (NTHR / PPR);
@@ -750,10 +762,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
 #pragma unroll
                 for (int q4 = 0; q4 < PE / 4; ++q4) {
                     const float4 a4 = *reinterpret_cast<const float4*>(stg + lr * ROWB + (piece * PE + q4 * 4) * 4);
-                    const float4 b4 = *reinterpret_cast<const float4*>(p.bias + co + q4 * 4);
-                    v[q4 * 4 + 0] = a4.x + b4.x; v[q4 * 4 + 1] = a4.y + b4.y; v[q4 * 4 + 2] = a4.z + b4.z; v[q4 * 4 + 3] = a4.w + b4.w;
+                    v[q4 * 4 + 0] = a4.x + bia[q4 * 4 + 0]; v[q4 * 4 + 1] = a4.y + bia[q4 * 4 + 1];
+                    v[q4 * 4 + 2] = a4.z + bia[q4 * 4 + 2]; v[q4 * 4 + 3] = a4.w + bia[q4 * 4 + 3];
                 }
-                if (p.res_add != nullptr) {
+                if (KD != 3 && p.res_add != nullptr) {
                     const long long ns = L / p.S_out;
 #pragma unroll
                     for (int q4 = 0; q4 < PE / 4; ++q4) {
