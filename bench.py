@@ -134,11 +134,11 @@ def roofline_of(plan, args):
     # HBM traffic of the same launches from PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
     # --pmc passes; collected offline with rocprofv3 on this command, see profiles/): bench.py cannot run the profiler
     traffic = traffic_note = None
-    tpath = os.path.join(ROOT, "profiles", "r01g_pmc_traffic_conv3.json")
+    tpath = os.path.join(ROOT, "profiles", "r01h_pmc_traffic_conv3.json")
     if os.path.exists(tpath) and args.dtype == "bf16" and args.batch == 32 and args.grid == 64 and args.dims == 3 and args.mc == 64:
         with open(tpath) as f:
             tj = json.load(f)
-        traffic, traffic_note = tj["hbm_bytes_per_launch"], "profiles/r01g_pmc_traffic_conv3.json (PMC FETCH_SIZE x2 + WRITE_SIZE, average per launch of the same conv3 launches)"
+        traffic, traffic_note = tj["hbm_bytes_per_launch"], "profiles/r01h_pmc_traffic_conv3.json (PMC FETCH_SIZE x2 + WRITE_SIZE, average per launch of the same conv3 launches)"
     alg_bytes = sum(p["bytes"] for p in conv3)
     return {
         "bound": "mfma", "kernel": "k_conv (3x3x3 implicit GEMM, LDS halo tile)", "achieved": achieved, "peak": peak,
