@@ -53,6 +53,7 @@ struct ConvK {
     int lgTW, lgTH;       // tile extents are powers of two
     float inv_ihw, inv_iw;  // 1 / (IH*IW), 1 / IW: exact small-integer division through one float multiply
     int cofast;           // cout tiles of one position tile on consecutive launch slots of one XCD
+    int coef_off;         // > 0: byte offset in LDS of the staged prologue coefficients [2][cin] (3-D tiles: one sample per tile)
 };
 
 // floor(a / d) for 0 <= a < 2^20 with inv = 1.0f / d: (a + 0.5) * inv is at least 0.5 / d away from an integer, the
@@ -268,6 +269,20 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
     constexpr int RS = (GB == 3) ? 9 : 3;          // LDS ring slots
     constexpr int DS = GB + 1;                     // store distance
     constexpr int LD = DS + 2;                     // load distance
+    // Folded GroupNorm affine of the prologue: read from global memory at every chunk's landing it is one exposed L2 round
+    // trip per chunk; a 3-D tile lies in one sample, so that sample's coefficients are staged in LDS once per tile.
+    const float* coef = nullptr;
+    if constexpr (NT != 1 && KD == 3) {
+        if (p.coef_off > 0 && p.pre_a != nullptr) {
+            float* cw_ = reinterpret_cast<float*>(smem + p.coef_off);
+            for (int i = tid; i < p.cin; i += NTHR) {
+                cw_[i] = p.pre_a[(size_t)n * p.cin + i];
+                cw_[p.cin + i] = p.pre_b[(size_t)n * p.cin + i];
+            }
+            coef = cw_;
+            __syncthreads();
+        }
+    }
     if constexpr (NT != 1) {
     if constexpr (PIPE) {
         RHO_LOAD_W(0, 0, 0);
@@ -323,9 +338,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                     if (spos[i] != -2) {
                         uint4 u = spos[i] >= 0 ? hv[i] : make_uint4(0u, 0u, 0u, 0u);
                         if (p.pre_a != nullptr && spos[i] >= 0) {
-                            const int smp = (KD == 3) ? n : ssmp[(KD == 3) ? 0 : i];
-                            const size_t co = (size_t)smp * p.cin + c + piece * PE;
-                            u = apply_pre<T>(u, p.pre_a + co, p.pre_b + co, p.pre_silu);
+                            if (KD == 3 && coef != nullptr) {
+                                u = apply_pre<T>(u, coef + c + piece * PE, coef + p.cin + c + piece * PE, p.pre_silu);
+                            } else {
+                                const int smp = (KD == 3) ? n : ssmp[(KD == 3) ? 0 : i];
+                                const size_t co = (size_t)smp * p.cin + c + piece * PE;
+                                u = apply_pre<T>(u, p.pre_a + co, p.pre_b + co, p.pre_silu);
+                            }
                         }
                         const int hp = (tid >> 2) + RPP * i;
                         *reinterpret_cast<uint4*>(halo + hp * PITCH + piece * 16) = u;
@@ -355,9 +374,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                             if (spos[i] != -2) {
                                 uint4 u = v[q];
                                 if (p.pre_a != nullptr && spos[i] >= 0) {
-                                    const int smp = (KD == 3) ? n : ssmp[(KD == 3) ? 0 : i];
-                                    const size_t co = (size_t)smp * p.cin + c + piece * PE;
-                                    u = apply_pre<T>(u, p.pre_a + co, p.pre_b + co, p.pre_silu);
+                                    if (KD == 3 && coef != nullptr) {
+                                        u = apply_pre<T>(u, coef + c + piece * PE, coef + p.cin + c + piece * PE, p.pre_silu);
+                                    } else {
+                                        const int smp = (KD == 3) ? n : ssmp[(KD == 3) ? 0 : i];
+                                        const size_t co = (size_t)smp * p.cin + c + piece * PE;
+                                        u = apply_pre<T>(u, p.pre_a + co, p.pre_b + co, p.pre_silu);
+                                    }
                                 }
                                 const int hp = (tid >> 2) + RPP * i;
                                 *reinterpret_cast<uint4*>(halo + hp * PITCH + piece * 16) = u;
@@ -1074,6 +1097,11 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
         k.stats = d.stats; k.tps = (int)tps;
     }
     size_t lds = (size_t)t.NP * PITCH + (size_t)WSLOTS * BM * PITCH;
+    k.coef_off = 0;
+    if (taps > 1 && d.kd == 3 && d.pre_a && lds + (size_t)2 * cin * sizeof(float) <= (BM == 128 ? lds_cap : lds_cap / 2)) {
+        k.coef_off = (int)lds;                                    // after the halo tile and the weight ring
+        lds += (size_t)2 * cin * sizeof(float);
+    }
     if (taps == 1)        // 1x1x1: double-buffered activations + weights + the prologue coefficients of one sample
         lds = (size_t)2 * 256 * PITCH + (size_t)2 * BM * PITCH + (d.pre_a ? (size_t)2 * k.cin * sizeof(float) : 0);
     if (d.stats) { const size_t lr = (size_t)(BM == 128 ? 512 : 256) * 16 * sizeof(float); if (lds < lr) lds = lr; }
