@@ -7,12 +7,13 @@ import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 4.0   # plan-building eager step + 1 warm-up + 2 timed replays
+PMC_DIR = sys.argv[3] if len(sys.argv) > 3 else "pmc"       # "pmc2": the training-step passes of tests/gpu_pmc2.sh (SQ counters only)
 
 
 def collect(sub):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     calls = collections.Counter()
-    files = glob.glob(os.path.join(ROOT, "gpurun_out/pmc", sub, "**/*counter_collection.csv"), recursive=True)
+    files = glob.glob(os.path.join(ROOT, "gpurun_out", PMC_DIR, sub, "**/*counter_collection.csv"), recursive=True)
     for f in sorted(files, key=os.path.getmtime)[-1:]:     # gpurun merges into the same directory: newest run only
         seen = set()
         for r in csv.DictReader(open(f)):
@@ -40,7 +41,10 @@ for k, v in sq.items():
         v["WAIT_INST_ANY_frac"] = v.get("SQ_WAIT_INST_ANY", 0) / v["SQ_WAVE_CYCLES"]
         v["WAIT_ANY_frac"] = v.get("SQ_WAIT_ANY", 0) / v["SQ_WAVE_CYCLES"]
     out[k[:70]] = v
-json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_sq_counters_summary.json"), "w"), indent=1)
+suffix = "" if PMC_DIR == "pmc" else "_train"
+json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc{suffix}_sq_counters_summary.json"), "w"), indent=1)
+if PMC_DIR != "pmc":
+    sys.exit(0)
 
 conv3 = [k for k in sq if "k_conv<" in k and "3, 3, 3" in k]
 fetch = sum(sq[k].get("FETCH_SIZE", 0.0) for k in conv3) * 1024.0 * 2.0
