@@ -332,6 +332,16 @@ def training_loss(model, x0: Tensor, t: Tensor, noise: Tensor, alpha_bar: Tensor
     return F.mse_loss(pred, noise)
 
 
+def discrete_parameter_rows(param_dict: Dict[str, Sequence[float]], batch_size: int) -> Tensor:
+    """rho_diffusion/utils.py:213-220 (sample_from_discrete_parameter_space, random=False): the first
+    ``batch_size`` rows of itertools.product over the parameter values - the labels DDPM.p_sample / generate
+    (rho_diffusion/diffusion/ddpm.py:319-360) hand to reverse_process."""
+    import itertools
+    _, values = zip(*param_dict.items())
+    combos = torch.tensor([v for v in itertools.product(*values)])
+    return combos[torch.arange(0, batch_size)]
+
+
 # --------------------------------------------------------------------------- GaussianDiffusionPipeline (SURVEY 8f #1)
 def gd_betas(schedule_name: str, num_steps: int):
     """rho_diffusion/diffusion/gaussian_diffusion.py:45-89 (get_named_beta_schedule / betas_for_alpha_bar), float64 numpy."""

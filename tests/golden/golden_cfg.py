@@ -24,3 +24,24 @@ UNET_CASES = {
     "full3d": (dict(in_channels=1, out_channels=1, model_channels=32, num_res_blocks=2, dims=3, data_shape=[8, 16, 16],
                     attention_resolutions=[16, 8], num_heads=4, use_scale_shift_norm=True), (2, 1, 8, 16, 16), None),
 }
+
+# ---- cases at the widths / structures the bench configurations run: recorded in g12_wide.npz
+# c5's parameter space (rho_diffusion/data/deep_galaxy.py:41-47): y [B, 4] = (s, m, t, c)
+DEEP_GALAXY_SPACE = {"s": [0.25, 0.5, 0.75, 1, 1.25, 1.5], "m": [0.25, 0.5, 0.75, 1, 1.25, 1.5],
+                     "t": list(range(300, 655, 5)), "c": [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13]}
+
+_base = dict(in_channels=1, out_channels=1, num_res_blocks=2, attention_resolutions=[16, 8], num_heads=4,
+             use_scale_shift_norm=True)
+WIDE_CASES = {
+    # c3's network (mc = 64: 512-channel levels, 1024-channel concatenations, ch = 128 heads) on a small grid
+    "wide3d": (dict(_base, model_channels=64, dims=3, data_shape=[4, 32, 32]), (1, 1, 4, 32, 32), None),
+    # c1 / c2's network on c1's grid
+    "wide2d": (dict(_base, model_channels=64, dims=2, data_shape=[64, 64]), (2, 1, 64, 64), None),
+    # c5's structure: 3-D mc = 32, conditioned through MultiEmbeddings(embedding_dim = 128) on y [B, 4]
+    "cond3d": (dict(_base, model_channels=32, dims=3, data_shape=[4, 16, 16], num_classes=25), (2, 1, 4, 16, 16), "galaxy"),
+}
+
+
+def galaxy_labels(B):
+    keys = list(DEEP_GALAXY_SPACE.keys())
+    return [[float(DEEP_GALAXY_SPACE[k][(3 * i + 5 * j + 1) % len(DEEP_GALAXY_SPACE[k])]) for j, k in enumerate(keys)] for i in range(B)]

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import torch
 
-from golden_cfg import PARAM_SPACE, UNET_CASES  # noqa: F401  (re-exported)
+from golden_cfg import DEEP_GALAXY_SPACE, PARAM_SPACE, UNET_CASES, WIDE_CASES, galaxy_labels  # noqa: F401  (re-exported)
 from detdata import det_normal, det_state_dict, det_uniform  # noqa: F401
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -50,6 +50,22 @@ def case_inputs(case: str):
     elif ykind == "preemb":
         y = det_normal((B, 4 * kw["model_channels"]), case + "y")
     return dict(kw), x, t, y
+
+
+def wide_case_inputs(case: str):
+    """(cfg, x, t, y, parameter_space) of a g12 case (tests/golden/make_golden.py gen_g12)."""
+    kw, xshape, ykind = WIDE_CASES[case]
+    x = det_normal(xshape, case + "x")
+    B = xshape[0]
+    t = torch.tensor([(37 * i + 11) % 1000 for i in range(B)])
+    y = torch.tensor(galaxy_labels(B), dtype=torch.float32) if ykind == "galaxy" else None
+    return dict(kw), x, t, y, (DEEP_GALAXY_SPACE if ykind == "galaxy" else None)
+
+
+def cosine(a: torch.Tensor, b: torch.Tensor) -> float:
+    a = a.detach().double().cpu().flatten()
+    b = b.detach().double().cpu().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-300))
 
 
 def grad_digest_of(g: torch.Tensor) -> np.ndarray:

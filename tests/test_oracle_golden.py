@@ -5,8 +5,8 @@ import pytest
 import torch
 from pytest import approx
 
-from helpers import (PARAM_SPACE, UNET_CASES, case_inputs, det_normal, det_state_dict, det_uniform,
-                     golden_template, grad_digest_of, load_golden, rel_l2)
+from helpers import (PARAM_SPACE, UNET_CASES, WIDE_CASES, case_inputs, det_normal, det_state_dict, det_uniform,
+                     golden_template, grad_digest_of, load_golden, rel_l2, wide_case_inputs)
 from oracle import ref_torch as R
 
 torch.set_num_threads(4)
@@ -139,6 +139,93 @@ def test_g5_ddpm(T):
         den, buf = R.reverse_process(model, tape[0], sched, tape[1:], None, num_checkpoints=3)
     assert rel_l2(den, torch.from_numpy(g[f"T{T}/denoised"])) < 1e-3  # chaotic chain: looser
     assert rel_l2(buf, torch.from_numpy(g[f"T{T}/buffer"])) < 1e-3
+
+
+@pytest.mark.parametrize("case", list(WIDE_CASES.keys()))
+def test_g12_unet_at_bench_widths(case):
+    """mc = 64 (512-channel levels, 1024-channel concatenations, ch = 128 heads) and c5's conditioned 3-D structure."""
+    g = load_golden("g12_wide.npz")
+    cfg, x, t, y, space = wide_case_inputs(case)
+    sd = det_state_dict(golden_template(g, case), case)
+    sd = {k: v.requires_grad_(True) for k, v in sd.items()}
+    torch.set_num_threads(8)
+    try:
+        pred = R.unet_forward(sd, cfg, x, t, y, space)
+        gold = torch.from_numpy(g[f"{case}/pred"])
+        assert pred.shape == gold.shape
+        assert rel_l2(pred, gold) < TOL
+        loss = torch.nn.functional.mse_loss(pred, det_normal(tuple(pred.shape), case + "tgt"))
+        assert abs(loss.item() - float(g[f"{case}/loss"])) < 1e-5
+        loss.backward()
+    finally:
+        torch.set_num_threads(4)
+    checked = 0
+    for k, v in sd.items():
+        key = f"{case}/grad/{k}"
+        if key in g.files and v.grad is not None:
+            d, ref = grad_digest_of(v.grad), g[key]
+            assert abs(d[0] - ref[0]) <= 1e-4 * ref[0] + 1e-6, k
+            checked += 1
+    assert checked > 300
+    if case == "cond3d":
+        assert any(k.startswith("cond_fn.embedding_layers.") for k in sd)
+
+
+def test_g13_cosine_ddpm_and_generate():
+    """DDPM on CosineBetaSchedule: T + 1 reverse steps (q9); generate(): labels from the parameter-space product."""
+    g = load_golden("g13_cosine_generate.npz")
+    g4 = load_golden("g4_unet.npz")
+    case, T = "tiny2d", 50
+    cfg, _, _, _ = case_inputs(case)
+    xshape = UNET_CASES[case][1]
+    sd = det_state_dict(golden_template(g4, case), case)
+    sched = R.cosine_schedule(T)
+    assert len(sched["alpha_bar_t"]) == T + 1
+    x0, eps = det_uniform(xshape, "x0", 0.0, 1.0), det_normal(xshape, "eps")
+    xt = R.q_sample(x0, torch.from_numpy(g["cos/t"]), eps, sched["alpha_bar_t"])
+    assert rel_l2(xt, torch.from_numpy(g["cos/q_sample"])) < 1e-6
+    tape = [det_normal(xshape, f"costape_{i}") for i in range(T + 1)]
+    with torch.no_grad():
+        model = lambda x, t, c: R.unet_forward(sd, cfg, x, t)  # noqa: E731
+        den, buf = R.reverse_process(model, tape[0], sched, tape[1:], None, num_checkpoints=3)
+    assert int(g["cos/draws"]) == 1                    # the reference drew 1 + (T - 1) of the T + 1 tape entries
+    assert rel_l2(den, torch.from_numpy(g["cos/denoised"])) < 1e-3
+    assert rel_l2(buf, torch.from_numpy(g["cos/buffer"])) < 1e-3
+
+    case, T = "tiny2d_multi", 20
+    cfg, _, _, _ = case_inputs(case)
+    sd = det_state_dict(golden_template(g4, case), case)
+    gshape = tuple(int(v) for v in g["gen/shape"])
+    assert gshape == (3, cfg["out_channels"]) + tuple(cfg["data_shape"])
+    labels = R.discrete_parameter_rows(PARAM_SPACE, gshape[0])
+    sched = R.linear_schedule(T, 1e-3, 0.02)
+    tape = [det_normal(gshape, f"gentape_{i}") for i in range(T)]
+    with torch.no_grad():
+        model = lambda x, t, c: R.unet_forward(sd, cfg, x, t, c, PARAM_SPACE)  # noqa: E731
+        den, _ = R.reverse_process(model, tape[0], sched, tape[1:], labels)
+    assert rel_l2(den, torch.from_numpy(g["gen/denoised"])) < 1e-3
+
+
+def test_g14_spherical_harmonic_fields():
+    """compute_spherical_harmonic of the reference (data/synthetic.py:81-124) on linspace(-2, 2, G)^3."""
+    g = load_golden("g14_spherical_harmonics.npz")
+    seen = 0
+    for key in g.files:
+        parts = key.split("/")
+        G = int(parts[0][1:])
+        l, m = (int(v[1:]) for v in parts[1].split("_"))
+        f = R.spherical_harmonic_field(l, m, G)[0].numpy()
+        if len(parts) == 2:
+            np.testing.assert_allclose(f, g[key], rtol=0, atol=2e-7)
+        elif parts[2] == "sub":
+            np.testing.assert_allclose(f[::4, ::4, ::4], g[key], rtol=0, atol=2e-7)
+        elif parts[2] == "row":
+            np.testing.assert_allclose(f[17, 42, :], g[key], rtol=0, atol=2e-7)
+        else:
+            mom = np.array([f.astype(np.float64).sum(), (f.astype(np.float64) ** 2).sum(), f.min(), f.max()])
+            np.testing.assert_allclose(mom, g[key], rtol=1e-6)
+        seen += 1
+    assert seen >= 11 + 12
 
 
 GD_TABLES = ("betas", "alphas_cumprod", "alphas_cumprod_prev", "alphas_cumprod_next", "sqrt_alphas_cumprod",
