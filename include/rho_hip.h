@@ -44,10 +44,11 @@ const char* rho_build_info(void);
 /* q_sample: x_t = sqrt(abar[t_b]) * x0 + sqrt(1 - abar[t_b]) * eps     (per batch element b)
  * replaces DDPM.forward_process, rho_diffusion/diffusion/ddpm.py:104-130 (+ the gather of
  * abstract_diffusion.py:171-220).  x0/eps/x_t: float32 [B, per_sample]; abar: float32 [T];
- * t: int64 [B].  nan_flag (optional, int32[1]) is set to 1 if any x_t is NaN: the device-side
- * form of the host check at ddpm.py:268-272. */
+ * t: int64 [B].  nan_flag (optional, int32[1]): bit 0 is set if any x_t is NaN (the device-side form of the host check at
+ * ddpm.py:268-272), bit 2 if some t[b] lies outside [0, table_len) - the reference raises IndexError there; the kernel then
+ * reads the clamped row instead of out-of-bounds memory.  table_len = number of entries of alpha_bar. */
 int rho_q_sample(const float* x0, const float* eps, float* x_t, const float* alpha_bar,
-                 const int64_t* t, int64_t batch, int64_t per_sample, int32_t* nan_flag, void* stream);
+                 const int64_t* t, int64_t batch, int64_t per_sample, int64_t table_len, int32_t* nan_flag, void* stream);
 
 /* p_sample_step: x <- clamp((x - beta/sqrt(1-abar) * eps_hat)/sqrt(alpha) + 0.8*sqrt(beta)*z, -1, 1)
  * replaces ddpm.py:210-218 (one reverse update, caller skips t == 0; z may be NULL => 0,
@@ -81,11 +82,35 @@ int rho_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr,
 
 /* ------------------------------------------------------------------ embeddings */
 
-/* out[b, :] = table[t[b], :]   (float32 [rows, dim] table; rows of the interleaved sin/cos
- * timestep embedding of rho_diffusion/models/common.py:27-43).  t is int64[B]; when
- * t_scalar_dev != NULL every b uses *t_scalar_dev (int32[1], device) instead. */
-int rho_embed_gather(const float* table, const int64_t* t, const int32_t* t_scalar_dev,
-                     float* out, int64_t batch, int64_t dim, int64_t rows, void* stream);
+/* Timestep embedding of UNet.forward (unet_v2.py:699-701): the interleaved sinusoid of models/common.py:27-43 for ANY integer
+ * t (no table, no range limit) followed by time_embed = Linear(dim -> edim), SiLU, Linear(edim -> edim) (unet_v2.py:521-525) and
+ * the label-embedding add (:702-719), one workgroup per sample:
+ *   pe[b, 2i] = sin(t_b / omega[i]), pe[b, 2i+1] = cos(t_b / omega[i])      omega: float32 [dim / 2] = wavelength^(2i / dim)
+ *   h = w0 pe + b0;   emb = w2 silu(h) + b2 (+ cond[b, :])
+ * t is int64[B]; when t_scalar_dev != NULL every b uses *t_scalar_dev (int32[1], device) instead (graph-replayable sampling
+ * step).  pe_out [B, dim] / h_out [B, edim] (optional) keep what the backward needs.  w0 == NULL: sinusoid only into pe_out
+ * (the registry layer SinusoidalPositionEmbedding, common.py:46-80). */
+int rho_timestep_embed(const float* omega, const int64_t* t, const int32_t* t_scalar_dev, const float* w0, const float* b0,
+                       const float* w2, const float* b2, const float* cond, float* pe_out, float* h_out, float* emb_out,
+                       int64_t batch, int64_t dim, int64_t edim, void* stream);
+
+/* MultiEmbeddings.forward (models/conditioning.py:115-139): out[b, :] = sum over keys i of tables[i][j, :] with j the position
+ * of y[b, i] in that key's value list (exact float equality, conditioning.py:132).  y float32 [B, nkeys] with row stride
+ * y_stride (y_stride == 1: one label per sample, shared by all keys as in the reference's 1-D branch); space = the value lists
+ * concatenated (float32), key i owning space[key_off[i] .. key_off[i+1]); tables = device array of nkeys float32 [n_i, dim]
+ * pointers.  idx_out (optional int32 [B, nkeys]) keeps the categories for the backward.  A label found in no list sets
+ * *err_flag |= 2 (the reference fails with a shape error there).  No host synchronisation (the reference's torch.where is one). */
+int rho_multi_embed(const float* y, int64_t y_stride, const float* space, const int32_t* key_off, const float* const* tables,
+                    int64_t nkeys, int64_t batch, int64_t dim, float* out, int32_t* idx_out, int32_t* err_flag, void* stream);
+
+/* Backward of rho_multi_embed: dtables[i][idx[b, i], :] += demb[b, :] (autograd of nn.Embedding, conditioning.py:58-60). */
+int rho_multi_embed_bwd(const float* demb, const int32_t* idx, float* const* dtables, int64_t nkeys, int64_t batch, int64_t dim,
+                        void* stream);
+
+/* random_timesteps (abstract_diffusion.py:163-169: randint(0, timesteps, (B,)) with replacement) on the device:
+ * out int64[n] uniform on [0, high), Philox4x32-10 stream (seed, offset) as rho_philox_normal (offset read from *offset_dev
+ * when given).  Removes the CPU draw + H2D copy of every training step. */
+int rho_randint(int64_t* out, int64_t n, int64_t high, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, void* stream);
 
 /* out[b, o] = bias[o] + sum_k act(x[b, k]) * w[o, k] (+ add[b, o])   all float32.
  * act_in: 0 = identity, 1 = SiLU.  act_out: 0 = identity, 1 = SiLU.
@@ -184,6 +209,25 @@ int rho_conv_nd_fwd(const rho_conv_desc* desc, void* stream);
  * kernels, 1x1x1 with positions-per-sample not a multiple of 256); callers then fall back to rho_gn_partial. */
 int64_t rho_conv_stats_tiles(const rho_conv_desc* desc);
 
+/* Test / profiling aid: the name of the kernel instantiation rho_conv_nd_fwd would launch for `desc`
+ * ("k_conv<bf16,3,3,3,BM=128,MAXP=5,NW=8,M16=1>"), written NUL-terminated into buf (cap >= 64).  Nothing is launched.
+ * Lets the parity tests assert that the variants they check against the oracle cover every variant a benchmark
+ * plan (BASELINE configs c3 / c5) launches.  Same return codes as rho_conv_nd_fwd. */
+int rho_conv_variant(const rho_conv_desc* desc, char* buf, int cap);
+
+/* ------------------------------------------------------------------ synthetic data */
+
+/* Spherical-harmonic density fields of the reference's SphericalHarmonicDataset, evaluated on the device in float64 and
+ * cast to float32 once (data/synthetic.py:45-124 compute_spherical_harmonic on the linspace(-2, 2, G)^3 grid of :172-174,
+ * complex min-max normalisation :115-119, abs :124, float32 :303):  out[b] = float32 [G, G, G] for (l, m) = lm[b] (int32 [B, 2]
+ * on the device; the field depends on |m| only).  workspace: rho_sph_harm_workspace_bytes(batch, grid) bytes.
+ * minmax_in (optional, float64 [B, 4] = min.real, min.imag, max.real, max.imag on the device) replaces the complex (min, max)
+ * pair of the normalisation - for m = 1, l >= 2 the reference's pair is decided by rounding noise of scipy (sph_harm.hip);
+ * minmax_out (optional, same layout) receives the pair used. */
+int64_t rho_sph_harm_workspace_bytes(int64_t batch, int64_t grid);
+int rho_sph_harm_fields(const int32_t* lm, int64_t batch, int64_t grid, float* out, void* workspace, const double* minmax_in,
+                        double* minmax_out, void* stream);
+
 /* ------------------------------------------------------------------ attention */
 
 /* Flash-style self attention, fp32 online softmax (QKVAttentionLegacy / QKVAttention,
@@ -210,6 +254,9 @@ int rho_ema_update(float* shadow, const float* param, int64_t n, float one_minus
  * bias gradient = per-channel sums of dy over all positions (the dY tiles pass through the kernel anyway; this replaces
  * a separate rho_chan_sum read of dy). */
 int rho_conv_nd_wgrad(const rho_conv_desc* desc, const void* dy, int64_t dy_width, float* dw, float* dbias, void* stream);
+
+/* As rho_conv_variant, for the kernel rho_conv_nd_wgrad would launch ("k_wgrad<bf16,3,3,3,MAXP=10>", "k_wgrad1<bf16>"). */
+int rho_conv_wgrad_variant(const rho_conv_desc* desc, int64_t dy_width, char* buf, int cap);
 
 /* dw buffer -> parameter-gradient layout [cout][cin][taps] float32 (undoing the qkv row gather). */
 int rho_wgrad_finalize(const float* dw, float* grad, int64_t cout, int64_t cin, int64_t taps, int64_t coutp,
@@ -263,9 +310,10 @@ int rho_abs_quantile(const float* x, int64_t batch, int64_t n, double q, void* w
 
 /* q_sample with explicit float32 coefficient tables: x_t = a[t_b] * x0 + b[t_b] * eps  (GaussianDiffusionPipeline.q_sample,
  * gaussian_diffusion.py:294-312, a = float(sqrt(abar)), b = float(sqrt(1-abar)) as _extract_into_tensor casts them).
- * x0 / eps / x_t: float32 [batch, per_sample]; t: int64 [batch] on the device. */
+ * x0 / eps / x_t: float32 [batch, per_sample]; t: int64 [batch] on the device; a t[b] outside [0, table_len) sets
+ * *err_flag |= 4 (optional flag) and reads the clamped row, as rho_q_sample. */
 int rho_q_sample_coef(const float* x0, const float* eps, float* x_t, const float* coef_a, const float* coef_b,
-                      const int64_t* t, int64_t batch, int64_t per_sample, void* stream);
+                      const int64_t* t, int64_t batch, int64_t per_sample, int64_t table_len, int32_t* err_flag, void* stream);
 
 /* One DDIM update for an x0-predicting model, gaussian_diffusion.py:654-702 (+ :400-415, :462-466), float32:
  *   s = max(quantile[b], 1);  x0 = clamp(model_out, -s, s) / s;  eps = (c_recip * x_t - x0) / c_recipm1

@@ -18,6 +18,7 @@
 //   * Weights ([tap][cout][cin], prepared once) stream through a 2-deep LDS ring, one tap ahead.
 //
 // Replaces conv_nd at every call site of rho_diffusion/models/unet_v2.py (see include/rho_hip.h).
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -941,8 +942,21 @@ namespace {
 
 using namespace rho_conv;
 
+// Variant query (rho_conv_variant): the same dispatch as a launch, but the chosen instantiation is written as text
+// instead of being launched - so the name can never disagree with what rho_conv_nd_fwd runs.
+struct VariantOut {
+    char* buf;
+    int cap;
+};
+thread_local VariantOut* g_variant = nullptr;
+
 template <typename T, int KD, int KH, int KW, int BM, int MAXP, int NW, bool M16 = false>
 int launch_one(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
+    if (g_variant != nullptr) {
+        snprintf(g_variant->buf, (size_t)g_variant->cap, "k_conv<%s,%d,%d,%d,BM=%d,MAXP=%d,NW=%d,M16=%d>", sizeof(T) == 2 ? "bf16" : "f32",
+                 KD, KH, KW, BM, MAXP, NW, (int)M16);
+        return 0;
+    }
     auto fn = k_conv<T, KD, KH, KW, BM, MAXP, NW, M16>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1119,6 +1133,16 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
 }
 
 extern "C" int rho_conv_nd_fwd(const rho_conv_desc* dp, void* stream) { return conv_impl(dp, stream, nullptr); }
+
+extern "C" int rho_conv_variant(const rho_conv_desc* dp, char* buf, int cap) {
+    if (!buf || cap < 64) return RHO_E_ARG;
+    buf[0] = 0;
+    VariantOut vo{buf, cap};
+    g_variant = &vo;
+    const int rc = conv_impl(dp, nullptr, nullptr);
+    g_variant = nullptr;
+    return rc;
+}
 
 extern "C" int64_t rho_conv_stats_tiles(const rho_conv_desc* dp) {
     int64_t t = 0;

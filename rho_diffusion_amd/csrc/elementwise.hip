@@ -18,11 +18,13 @@ extern "C" const char* rho_build_info(void) { return "librho_hip gfx950 (CDNA4) 
 __global__ __launch_bounds__(256) void k_q_sample(const float4* __restrict__ x0, const float4* __restrict__ eps,
                                                   float4* __restrict__ xt, const float* __restrict__ abar,
                                                   const int64_t* __restrict__ t, int64_t per4, int64_t total4,
-                                                  int32_t* nan_flag) {
-    bool bad = false;
+                                                  int64_t table_len, int32_t* nan_flag) {
+    bool bad = false, oob = false;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = i / per4;
-        const float ab = abar[t[b]];
+        int64_t tb = t[b];
+        if (tb < 0 || tb >= table_len) { oob = true; tb = tb < 0 ? 0 : table_len - 1; }   // the reference raises IndexError
+        const float ab = abar[tb];
         const float sa = sqrtf(ab), sb = sqrtf(1.0f - ab);
         const float4 a = x0[i], e = eps[i];
         float4 r;
@@ -33,16 +35,22 @@ __global__ __launch_bounds__(256) void k_q_sample(const float4* __restrict__ x0,
         bad |= (r.x != r.x) | (r.y != r.y) | (r.z != r.z) | (r.w != r.w);
         xt[i] = r;
     }
-    if (nan_flag != nullptr && __any(bad)) {
-        if ((threadIdx.x & 63) == 0) atomicOr(nan_flag, 1);
+    const int any_bad = __any(bad), any_oob = __any(oob);
+    if (nan_flag != nullptr && (any_bad || any_oob)) {
+        if ((threadIdx.x & 63) == 0) atomicOr(nan_flag, (any_bad ? 1 : 0) | (any_oob ? 4 : 0));
     }
 }
 
 __global__ void k_q_sample_tail(const float* x0, const float* eps, float* xt, const float* abar, const int64_t* t,
-                                int64_t per_sample, int64_t batch, int64_t tail_start, int32_t* nan_flag) {
+                                int64_t per_sample, int64_t batch, int64_t table_len, int32_t* nan_flag) {
     // scalar path for per_sample % 4 != 0 (only tiny test shapes)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < batch * per_sample; i += (int64_t)gridDim.x * blockDim.x) {
-        const float ab = abar[t[i / per_sample]];
+        int64_t tb = t[i / per_sample];
+        if (tb < 0 || tb >= table_len) {
+            if (nan_flag) atomicOr(nan_flag, 4);
+            tb = tb < 0 ? 0 : table_len - 1;
+        }
+        const float ab = abar[tb];
         const float r = sqrtf(ab) * x0[i] + sqrtf(1.0f - ab) * eps[i];
         if (r != r && nan_flag) atomicOr(nan_flag, 1);
         xt[i] = r;
@@ -50,15 +58,15 @@ __global__ void k_q_sample_tail(const float* x0, const float* eps, float* xt, co
 }
 
 extern "C" int rho_q_sample(const float* x0, const float* eps, float* x_t, const float* alpha_bar, const int64_t* t,
-                            int64_t batch, int64_t per_sample, int32_t* nan_flag, void* stream) {
-    if (!x0 || !eps || !x_t || !alpha_bar || !t || batch <= 0 || per_sample <= 0) return RHO_E_ARG;
+                            int64_t batch, int64_t per_sample, int64_t table_len, int32_t* nan_flag, void* stream) {
+    if (!x0 || !eps || !x_t || !alpha_bar || !t || batch <= 0 || per_sample <= 0 || table_len <= 0) return RHO_E_ARG;
     if (per_sample % 4 == 0 && (((uintptr_t)x0 | (uintptr_t)eps | (uintptr_t)x_t) & 15) == 0) {
         const int64_t total4 = batch * per_sample / 4;
         hipLaunchKernelGGL(k_q_sample, dim3(grid_for(total4, 256)), dim3(256), 0, as_stream(stream), (const float4*)x0,
-                           (const float4*)eps, (float4*)x_t, alpha_bar, t, per_sample / 4, total4, nan_flag);
+                           (const float4*)eps, (float4*)x_t, alpha_bar, t, per_sample / 4, total4, table_len, nan_flag);
     } else {
         hipLaunchKernelGGL(k_q_sample_tail, dim3(grid_for(batch * per_sample, 256)), dim3(256), 0, as_stream(stream), x0, eps,
-                           x_t, alpha_bar, t, per_sample, batch, (int64_t)0, nan_flag);
+                           x_t, alpha_bar, t, per_sample, batch, table_len, nan_flag);
     }
     RHO_LAUNCH_CHECK();
     return 0;
@@ -241,26 +249,6 @@ extern "C" int rho_adamw(float* p, const float* g, float* m, float* v, int64_t n
 }
 
 // ----------------------------------------------------------------------------- embeddings
-__global__ void k_embed_gather(const float* __restrict__ table, const int64_t* __restrict__ t,
-                               const int32_t* __restrict__ t_scalar, float* __restrict__ out, int64_t batch, int64_t dim,
-                               int64_t rows) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= batch * dim) return;
-    const int64_t b = i / dim, d = i % dim;
-    int64_t row = t_scalar ? (int64_t)(*t_scalar) : t[b];
-    row = row < 0 ? 0 : (row >= rows ? rows - 1 : row);
-    out[i] = table[row * dim + d];
-}
-
-extern "C" int rho_embed_gather(const float* table, const int64_t* t, const int32_t* t_scalar_dev, float* out,
-                                int64_t batch, int64_t dim, int64_t rows, void* stream) {
-    if (!table || !out || (!t && !t_scalar_dev) || batch <= 0 || dim <= 0 || rows <= 0) return RHO_E_ARG;
-    hipLaunchKernelGGL(k_embed_gather, dim3((unsigned)((batch * dim + 255) / 256)), dim3(256), 0, as_stream(stream), table, t,
-                       t_scalar_dev, out, batch, dim, rows);
-    RHO_LAUNCH_CHECK();
-    return 0;
-}
-
 // One wave per output feature: the weight row stays in registers while the wave walks the batch.
 // (B <= a few hundred, in_dim <= 1024: launch-latency bound)
 template <int MAXK>  // in_dim <= 64*MAXK

@@ -195,22 +195,28 @@ extern "C" int rho_ddim_step(const float* x_t, const float* model_out, const flo
 // mul, mul, add without contraction like the reference's tensor expression)
 __global__ __launch_bounds__(256) void k_q_sample_coef(const float* __restrict__ x0, const float* __restrict__ eps, float* __restrict__ xt,
                                                        const float* __restrict__ ca, const float* __restrict__ cb,
-                                                       const int64_t* __restrict__ t, int64_t per_sample, int64_t total) {
+                                                       const int64_t* __restrict__ t, int64_t per_sample, int64_t total,
+                                                       int64_t table_len, int32_t* err_flag) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t tb = t[i / per_sample];
+        int64_t tb = t[i / per_sample];
+        if (tb < 0 || tb >= table_len) {               // the reference's table gather raises IndexError
+            if (err_flag != nullptr) atomicOr(err_flag, 4);
+            tb = tb < 0 ? 0 : table_len - 1;
+        }
         const float p0 = ca[tb] * x0[i], p1 = cb[tb] * eps[i];
         xt[i] = p0 + p1;
     }
 }
 
 extern "C" int rho_q_sample_coef(const float* x0, const float* eps, float* x_t, const float* coef_a, const float* coef_b,
-                                 const int64_t* t, int64_t batch, int64_t per_sample, void* stream) {
-    if (!x0 || !eps || !x_t || !coef_a || !coef_b || !t || batch <= 0 || per_sample <= 0) return RHO_E_ARG;
+                                 const int64_t* t, int64_t batch, int64_t per_sample, int64_t table_len, int32_t* err_flag,
+                                 void* stream) {
+    if (!x0 || !eps || !x_t || !coef_a || !coef_b || !t || batch <= 0 || per_sample <= 0 || table_len <= 0) return RHO_E_ARG;
     const int64_t total = batch * per_sample;
     int64_t g = (total + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(k_q_sample_coef, dim3((unsigned)g), dim3(256), 0, as_stream(stream), x0, eps, x_t, coef_a, coef_b, t, per_sample,
-                       total);
+                       total, table_len, err_flag);
     RHO_LAUNCH_CHECK();
     return 0;
 }

@@ -12,6 +12,7 @@
 //     fragments (8 consecutive k per lane) are produced by gfx950's transposing LDS read
 //     ds_read_b64_tr_b16 straight from the row-major tiles - no transposed copies.
 // The exact-f32 variant (v_mfma_f32_32x32x2_f32) needs one k per lane, i.e. plain ds_read_b32.
+#include <cstdio>
 #include <type_traits>
 
 #include "conv_common.h"
@@ -500,8 +501,19 @@ __global__ __launch_bounds__(256) void k_wgrad1(const WgradK p, long long npos, 
 namespace {
 using namespace rho_conv;
 
+struct VariantOut {
+    char* buf;
+    int cap;
+};
+thread_local VariantOut* g_wvariant = nullptr;      // see rho_conv_variant (conv.hip)
+
 template <typename T, int KD, int KH, int KW>
 int launch_wgrad(const WgradK& k, int maxp, dim3 grid, size_t lds, hipStream_t st) {
+    if (g_wvariant != nullptr) {
+        snprintf(g_wvariant->buf, (size_t)g_wvariant->cap, "k_wgrad<%s,%d,%d,%d,MAXP=%d>", sizeof(T) == 2 ? "bf16" : "f32", KD, KH, KW,
+                 maxp <= 10 ? 10 : 28);
+        return 0;
+    }
     if (maxp <= 10) {
         auto fn = k_wgrad<T, KD, KH, KW, 10>;
         if (lds > 64 * 1024) {
@@ -541,8 +553,24 @@ inline int ilog2(int v) {
 // (channels-last, row width dy_width >= cout, extra channels must be zero); dw is an fp32 buffer
 // [taps][coutp][c1+c2] that this call ACCUMULATES into (zero it first).  up_h/up_w are not supported:
 // materialise the upsampled input (rho_upsample2x) and pass it as x1.
+static int wgrad_impl(const rho_conv_desc* dp, const void* dy, int64_t dy_width, float* dw, float* dbias, void* stream);
+
 extern "C" int rho_conv_nd_wgrad(const rho_conv_desc* dp, const void* dy, int64_t dy_width, float* dw, float* dbias, void* stream) {
     if (!dp || !dy || !dw) return RHO_E_ARG;
+    return wgrad_impl(dp, dy, dy_width, dw, dbias, stream);
+}
+
+extern "C" int rho_conv_wgrad_variant(const rho_conv_desc* dp, int64_t dy_width, char* buf, int cap) {
+    if (!dp || !buf || cap < 64) return RHO_E_ARG;
+    buf[0] = 0;
+    VariantOut vo{buf, cap};
+    g_wvariant = &vo;
+    const int rc = wgrad_impl(dp, nullptr, dy_width, nullptr, nullptr, nullptr);
+    g_wvariant = nullptr;
+    return rc;
+}
+
+static int wgrad_impl(const rho_conv_desc* dp, const void* dy, int64_t dy_width, float* dw, float* dbias, void* stream) {
     const rho_conv_desc& d = *dp;
     if (!d.x1) return RHO_E_ARG;
     if (d.dtype != RHO_F32 && d.dtype != RHO_BF16) return RHO_E_ARG;
@@ -592,6 +620,10 @@ extern "C" int rho_conv_nd_wgrad(const rho_conv_desc* dp, const void* dy, int64_
         splits = cdiv(tiles_total, tpb);
         if (cdiv(d.coutp, 64) > 65535 || cdiv(cin, 128) > 65535) return RHO_E_SHAPE;
         dim3 grid((unsigned)splits, (unsigned)cdiv(d.coutp, 64), (unsigned)cdiv(cin, 128));
+        if (g_wvariant != nullptr) {
+            snprintf(g_wvariant->buf, (size_t)g_wvariant->cap, "k_wgrad1<bf16>");
+            return 0;
+        }
         hipLaunchKernelGGL(k_wgrad1, grid, dim3(256), (size_t)(4 * 128 * XP + 128 * DYP), as_stream(stream), k1, npos, tiles_total, tpb);
         hipError_t e1 = hipGetLastError();
         return e1 == hipSuccess ? 0 : (int)e1;

@@ -58,6 +58,10 @@ class DDPM(AbstractDiffusionPipeline):
         # where the step is launch-bound (2-D 64^2: ~190 launches of a few microseconds each); bit-identical to the
         # eager loop.  Falls back to the eager loop if capture is not possible (e.g. label lookups that synchronise).
         self.hip_graph_sampling = os.environ.get("RHO_HIP_GRAPH", "1") != "0"
+        # training_step: draw t on the device (rho_randint, Philox stream of this rank) instead of the reference's CPU
+        # torch.randint + H2D copy (abstract_diffusion.py:163-169, ddpm.py:264).  Off by default: the CPU draw follows
+        # torch.manual_seed like the reference; DPTrainer / bench.py switch it on.
+        self.device_timesteps = os.environ.get("RHO_DEVICE_TIMESTEPS", "0") == "1"
 
     # ------------------------------------------------------------------ noise
     def noise(self, data: Tensor) -> Tensor:
@@ -75,7 +79,12 @@ class DDPM(AbstractDiffusionPipeline):
         batch_size = data.size(0)
         self.schedule.dtype = data.dtype
         if t is None:
-            t = self.random_timesteps(batch_size)
+            t = self._draw_timesteps(batch_size, data.device)
+        n_rows = len(self.schedule["alpha_bar_t"])
+        if not t.is_cuda and t.numel() and (int(t.max()) >= n_rows or int(t.min()) < -n_rows):
+            # same failure as the reference's table gather (abstract_diffusion.py:216-220) when `timesteps` exceeds the
+            # schedule length; timesteps already on the device are checked by the kernel instead (flag bit 2, see _check_nan)
+            raise IndexError(f"index {int(t.max())} is out of bounds for dimension 0 with size {n_rows}")
         t = t.reshape(-1).to(device=data.device, dtype=torch.int64).contiguous()
         x0 = data.float().contiguous()
         noise = self.noise(x0)
@@ -188,12 +197,25 @@ class DDPM(AbstractDiffusionPipeline):
         return True
 
     # ------------------------------------------------------------------ training
-    def _check_nan(self) -> None:
+    def _draw_timesteps(self, batch_size: int, device) -> Tensor:
+        """random_timesteps on the device when ``device_timesteps`` is set (no H2D copy), else the reference's CPU draw."""
+        if self.device_timesteps and torch.device(device).type == "cuda" and "random_timesteps" not in self.__dict__:
+            t = ops.randint(batch_size, int(self.timesteps), self.noise_seed ^ 0x5DEECE66D, self._noise_offset, device=device)
+            self._noise_offset += (batch_size + 3) // 4
+            return t
+        return self.random_timesteps(batch_size).to(device)
+
+    def _check_nan(self, force: bool = False) -> None:
         """Device-side form of the per-step host check at ddpm.py:268-272: the flag is set by the
-        q_sample kernel and polled every ``nan_check_every`` steps instead of syncing each step."""
+        q_sample kernel and polled every ``nan_check_every`` steps instead of syncing each step.
+        Bit 0: NaN in the noised data; bit 2: a timestep outside the schedule table (IndexError in the reference)."""
         self._steps_seen += 1
-        if self._nan_flag is not None and self._steps_seen % self.nan_check_every == 0:
-            if int(self._nan_flag.item()) != 0:
+        if self._nan_flag is not None and (force or self._steps_seen % self.nan_check_every == 0):
+            v = int(self._nan_flag.item())
+            if v & 4:
+                self._nan_flag.zero_()
+                raise IndexError(f"a timestep is out of bounds for the schedule tables of size {len(self.schedule['alpha_bar_t'])}")
+            if v & 1:
                 print("Error: Noised data contains NaNs. Check your noise scheduler.")
                 import sys
                 sys.exit(0)
@@ -211,7 +233,7 @@ class DDPM(AbstractDiffusionPipeline):
         self.data_shape = data.shape
         self.data_dtype = data.dtype
         batch_size = data.size(0)
-        t = self.random_timesteps(batch_size).to(data.device)
+        t = self._draw_timesteps(batch_size, data.device)
         x_data, noise = self.forward_process(data, t)
         self._check_nan()
         if labels is not None:

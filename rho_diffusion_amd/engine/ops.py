@@ -43,7 +43,7 @@ def q_sample(x0: Tensor, eps: Tensor, t: Tensor, alpha_bar: Tensor, out: Optiona
         raise RhoHipError("t must be an int64 GPU tensor")
     out = torch.empty_like(x0) if out is None else out
     B = x0.shape[0]
-    check(hip.lib().rho_q_sample(ptr(x0), ptr(eps), ptr(out), ptr(alpha_bar), ptr(t), B, x0.numel() // B,
+    check(hip.lib().rho_q_sample(ptr(x0), ptr(eps), ptr(out), ptr(alpha_bar), ptr(t), B, x0.numel() // B, alpha_bar.numel(),
                                  ptr(nan_flag), stream()), "rho_q_sample")
     return out
 
@@ -57,15 +57,16 @@ def p_sample_step(x: Tensor, eps_hat: Tensor, z: Optional[Tensor], coef_table: T
     return x
 
 
-def q_sample_coef(x0: Tensor, eps: Tensor, t: Tensor, coef_a: Tensor, coef_b: Tensor, out: Optional[Tensor] = None) -> Tensor:
+def q_sample_coef(x0: Tensor, eps: Tensor, t: Tensor, coef_a: Tensor, coef_b: Tensor, out: Optional[Tensor] = None,
+                  err_flag: Optional[Tensor] = None) -> Tensor:
     """x_t = a[t] * x0 + b[t] * eps with explicit float32 tables (GaussianDiffusionPipeline.q_sample)."""
     x0, eps, coef_a, coef_b = _f32c(x0, "x0"), _f32c(eps, "eps"), _f32c(coef_a, "coef_a"), _f32c(coef_b, "coef_b")
     if t.dtype != torch.int64 or not t.is_cuda:
         raise RhoHipError("t must be an int64 GPU tensor")
     out = torch.empty_like(x0) if out is None else out
     B = x0.shape[0]
-    check(hip.lib().rho_q_sample_coef(ptr(x0), ptr(eps), ptr(out), ptr(coef_a), ptr(coef_b), ptr(t), B, x0.numel() // B, stream()),
-          "rho_q_sample_coef")
+    check(hip.lib().rho_q_sample_coef(ptr(x0), ptr(eps), ptr(out), ptr(coef_a), ptr(coef_b), ptr(t), B, x0.numel() // B,
+                                      min(coef_a.numel(), coef_b.numel()), ptr(err_flag), stream()), "rho_q_sample_coef")
     return out
 
 
@@ -119,15 +120,57 @@ def adamw(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, beta1: float, b
 
 
 # ----------------------------------------------------------------------------- embeddings
-def embed_gather(table: Tensor, t: Optional[Tensor], batch: int, t_scalar_dev: Optional[Tensor] = None,
-                 out: Optional[Tensor] = None) -> Tensor:
-    _f32c(table, "table")
-    rows, dim = table.shape
-    out = torch.empty(batch, dim, dtype=torch.float32, device=table.device) if out is None else out
+def sinusoid_frequencies(dim: int, wavelength: int = 10000, device=None) -> Tensor:
+    """omega_i = wavelength^(2i / dim), i = 0 .. dim/2 - 1, float32: the denominators of the timestep sinusoid
+    (models/common.py:38 evaluates this very expression; the kernel divides t by it)."""
+    if dim % 2:
+        raise RhoHipError("`dim` should be dividable by 2.")
+    i = torch.arange(dim // 2)
+    return torch.pow(wavelength, 2 * i / dim).to(device=device, dtype=torch.float32).contiguous()
+
+
+def timestep_embed(omega: Tensor, t: Optional[Tensor], batch: int, *, t_scalar_dev: Optional[Tensor] = None,
+                   w0: Optional[Tensor] = None, b0: Optional[Tensor] = None, w2: Optional[Tensor] = None,
+                   b2: Optional[Tensor] = None, cond: Optional[Tensor] = None, pe_out: Optional[Tensor] = None,
+                   h_out: Optional[Tensor] = None, emb_out: Optional[Tensor] = None):
+    """Sinusoid of any integer t (+ the time_embed MLP and the label-embedding add when w0 is given): rho_timestep_embed."""
+    _f32c(omega, "omega")
+    dim = 2 * omega.numel()
     if t is not None and (t.dtype != torch.int64 or not t.is_cuda or not t.is_contiguous()):
         raise RhoHipError("t must be a contiguous int64 GPU tensor")
-    check(hip.lib().rho_embed_gather(ptr(table), ptr(t), ptr(t_scalar_dev), ptr(out), batch, dim, rows, stream()),
-          "rho_embed_gather")
+    edim = w0.shape[0] if w0 is not None else 0
+    if pe_out is None:
+        pe_out = torch.empty(batch, dim, dtype=torch.float32, device=omega.device)
+    if w0 is not None and emb_out is None:
+        emb_out = torch.empty(batch, edim, dtype=torch.float32, device=omega.device)
+    check(hip.lib().rho_timestep_embed(ptr(omega), ptr(t), ptr(t_scalar_dev), ptr(w0), ptr(b0), ptr(w2), ptr(b2), ptr(cond),
+                                       ptr(pe_out), ptr(h_out), ptr(emb_out), batch, dim, edim, stream()), "rho_timestep_embed")
+    return pe_out if w0 is None else emb_out
+
+
+def randint(n: int, high: int, seed: int, offset: int = 0, offset_dev: Optional[Tensor] = None, out: Optional[Tensor] = None,
+            device=None) -> Tensor:
+    """Uniform int64 on [0, high) from the Philox stream (seed, offset): random_timesteps on the device."""
+    out = torch.empty(n, dtype=torch.int64, device=device) if out is None else out
+    hip.require_gpu(out, "out")
+    check(hip.lib().rho_randint(ptr(out), n, high, seed & (2 ** 64 - 1), offset, ptr(offset_dev), stream()), "rho_randint")
+    return out
+
+
+def sph_harm_fields(lm: Tensor, grid: int, out: Optional[Tensor] = None, minmax_in: Optional[Tensor] = None,
+                    minmax_out: Optional[Tensor] = None) -> Tensor:
+    """Spherical-harmonic density fields float32 [B, G, G, G] for (l, m) = lm[b] (int32 [B, 2] on the GPU)."""
+    hip.require_gpu(lm, "lm")
+    if lm.dtype != torch.int32 or lm.dim() != 2 or lm.shape[1] != 2 or not lm.is_contiguous():
+        raise RhoHipError("lm must be a contiguous int32 [B, 2] tensor")
+    B = lm.shape[0]
+    out = torch.empty(B, grid, grid, grid, dtype=torch.float32, device=lm.device) if out is None else out
+    ws = torch.empty(int(hip.lib().rho_sph_harm_workspace_bytes(B, grid)) // 8, dtype=torch.float64, device=lm.device)
+    for name, mm in (("minmax_in", minmax_in), ("minmax_out", minmax_out)):
+        if mm is not None and (mm.dtype != torch.float64 or tuple(mm.shape) != (B, 4) or not mm.is_cuda or not mm.is_contiguous()):
+            raise RhoHipError(f"{name} must be a contiguous float64 [B, 4] GPU tensor")
+    check(hip.lib().rho_sph_harm_fields(ptr(lm), B, grid, ptr(out), ptr(ws), ptr(minmax_in), ptr(minmax_out), stream()),
+          "rho_sph_harm_fields")
     return out
 
 
@@ -241,6 +284,19 @@ def conv_out_shape(x_shape, kernel, stride_hw, up_hw):
     ho = H * 2 if up_hw[0] else (H + 2 * (kh // 2) - kh) // stride_hw[0] + 1
     wo = W * 2 if up_hw[1] else (W + 2 * (kw // 2) - kw) // stride_hw[1] + 1
     return N, D, ho, wo
+
+
+def conv_variant(desc: ConvDesc) -> str:
+    """Name of the k_conv instantiation rho_conv_nd_fwd launches for ``desc`` (nothing is launched)."""
+    buf = C.create_string_buffer(128)
+    check(hip.lib().rho_conv_variant(C.byref(desc), buf, 128), "rho_conv_variant")
+    return buf.value.decode()
+
+
+def conv_wgrad_variant(desc: ConvDesc, dy_width: int) -> str:
+    buf = C.create_string_buffer(128)
+    check(hip.lib().rho_conv_wgrad_variant(C.byref(desc), dy_width, buf, 128), "rho_conv_wgrad_variant")
+    return buf.value.decode()
 
 
 def conv_launch(desc: ConvDesc) -> None:

@@ -176,8 +176,8 @@ class UNetEngine:
         self._convs: List[_ConvW] = []
         self._conv_of: Dict[int, _ConvW] = {}
         self._film_blocks: List[nn.Module] = []
-        self._sin_table: Optional[Tensor] = None
-        self._sin_rows = 0
+        self._omega: Optional[Tensor] = None
+        self._cond_dev = None      # device-side tables of the label embedding (MultiEmbeddings), built on first use
         self._param_version = -1
         self._ptr_sig = None
         self._last_train_plan: Optional["_Plan"] = None
@@ -275,16 +275,52 @@ class UNetEngine:
             off += n
         self._param_version = v
 
-    def sin_table(self, rows: int) -> Tensor:
-        """Rows t = 0..rows-1 of the interleaved sin/cos embedding (models/common.py), built on the
-        host exactly as the reference evaluates it and gathered on the device per step."""
-        if self._sin_table is None or self._sin_rows < rows:
-            from ..models.common import sinosoidal_position_embedding
-            rows = max(rows, 1024)
-            tab = sinosoidal_position_embedding(torch.arange(rows), self.mc)
-            self._sin_table = tab.to(self.device).contiguous()
-            self._sin_rows = rows
-        return self._sin_table
+    def omega(self) -> Tensor:
+        """Denominators wavelength^(2i / mc) of the timestep sinusoid (float32 [mc / 2]); the kernel evaluates sin / cos for any t."""
+        if self._omega is None:
+            self._omega = ops.sinusoid_frequencies(self.mc, 10000, self.device)
+        return self._omega
+
+    def err_flag(self) -> Tensor:
+        """int32[1] device flag the kernels OR error bits into (bit 1: label not in the parameter space); polled by ``check_errors``."""
+        if getattr(self, "_err_flag", None) is None:
+            self._err_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        return self._err_flag
+
+    def check_errors(self) -> None:
+        """Host poll of the device error flag (one synchronisation: call it outside the hot loop)."""
+        if getattr(self, "_err_flag", None) is not None:
+            v = int(self._err_flag.item())
+            if v & 2:
+                self._err_flag.zero_()
+                raise IndexError("MultiEmbeddings: a label value is not in the parameter space (conditioning.py:132)")
+
+    def cond_device_tables(self):
+        """Device-side description of ``model.cond_fn`` when it is a MultiEmbeddings (conditioning.py:31-139): the value lists of
+        the parameter space concatenated as float32, their offsets, and a pointer array of the embedding tables.  None for any
+        other cond_fn module (evaluated as given)."""
+        from ..models.conditioning import MultiEmbeddings
+        fn = getattr(self.model, "cond_fn", None)
+        if not isinstance(fn, MultiEmbeddings) or fn.parameter_space is None or len(fn.embedding_layers) == 0:
+            return None
+        weights = [layer.weight for layer in fn.embedding_layers.values()]
+        sig = tuple(w.data_ptr() for w in weights)
+        if self._cond_dev is not None and self._cond_dev["sig"] == sig:
+            return self._cond_dev
+        keys = list(fn.embedding_layers.keys())
+        if len(keys) > 16:
+            return None
+        vals, off = [], [0]
+        for k in keys:
+            v = torch.tensor(fn.parameter_space[k]).to(torch.float32)      # torch.tensor(list): the reference's conversion (:131)
+            vals.append(v)
+            off.append(off[-1] + v.numel())
+        dev = self.device
+        self._cond_dev = dict(sig=sig, nkeys=len(keys), weights=weights,
+                              space=torch.cat(vals).to(dev).contiguous(),
+                              key_off=torch.tensor(off, dtype=torch.int32, device=dev),
+                              tables=torch.tensor(list(sig), dtype=torch.int64, device=dev))
+        return self._cond_dev
 
     def param_order(self) -> List[nn.Parameter]:
         """Embedding-path parameters first (their gradients complete last), then every other parameter in
@@ -344,6 +380,8 @@ class _Plan:
         self.keep: List[object] = []   # descriptors / tensors referenced by raw pointers
         self.tstats: Dict[int, Tuple[Tensor, int]] = {}   # conv output data_ptr -> (fused statistics buffer, tiles per sample)
         self.nodes: List[dict] = []
+        self.fwd_descs: List[object] = []          # rho_conv_desc of every forward / data-gradient launch (variants())
+        self.wgrad_descs: List[tuple] = []         # (forward-shaped descriptor, dY row width) of every weight-gradient launch
         self.cond_src = None
         L = hip.lib()
         self.L = L
@@ -361,6 +399,7 @@ class _Plan:
             return t
 
         # ---- embedding chain: table gather -> Linear -> (SiLU) Linear (+cond) -> (SiLU) batched FiLM GEMV
+        self.t_in = buf(B, dtype=torch.int64)
         self.sin_in = buf(B, eng.mc, dtype=torch.float32)
         self.emb_h = buf(B, e, dtype=torch.float32)     # PRE-activation of time_embed[0]; the consumer applies SiLU
         self.emb = buf(B, e, dtype=torch.float32)
@@ -376,8 +415,9 @@ class _Plan:
             self.ops.append(lambda s, a=args: L.rho_linear(*a, s))
             self.info.append(dict(kind="linear", flops=2.0 * Bn * K * O, bytes=4.0 * (O * K + Bn * (K + O))))
 
-        op_linear(self.sin_in, te0.weight, te0.bias, None, self.emb_h, False, False)
-        op_linear(self.emb_h, te2.weight, te2.bias, self.cond, self.emb, True, False)
+        # sinusoid + Linear + SiLU + Linear (+ label embedding) run as ONE launch at the head of run() (rho_timestep_embed: its
+        # timestep pointer changes per call); sin_in / emb_h are kept for the backward
+        self.cond_idx = buf(B, 16, dtype=torch.int32) if has_y else None
         if eng.film_total:
             op_linear(self.emb, eng.film_w, eng.film_b, None, self.film, True, False)
 
@@ -463,6 +503,7 @@ class _Plan:
                     d.stats = sbuf.data_ptr()
                     self.tstats[y.data_ptr()] = (sbuf, tiles)
             self.keep.append(d)
+            self.fwd_descs.append(d)
             self.ops.append(lambda s, d=d: L.rho_conv_nd_fwd(C.byref(d), s))
             npos_out = N * Do * Ho * Wo
             npos_in = x1.numel() // x1.shape[-1]
@@ -650,6 +691,7 @@ class _Plan:
             d = ops.make_conv_desc(x1, x2, cw.w, cw.b, kernel=cw.kernel, cout=cw.cout, split=cw.cout, y=dY, y2=None,
                                    stride_hw=node["stride_hw"], pre_silu=False)
             self.keep.append(d)
+            self.wgrad_descs.append((d, dyw))
             nw = cw.taps * cw.coutp * cw.cinp
             dwv = dwbuf[:nw]
             cbv = c_tmp[:max(dyw, cw.coutp)]
@@ -682,6 +724,7 @@ class _Plan:
                 dact = pool.get(tshape, dt)       # gradient of the activated / upsampled tensor
                 d = ops.make_conv_desc(dY, None, cw.wd, cw.zero_bias, split=cin, y=dact, y2=None, **common)
                 self.keep.append(d)
+                self.fwd_descs.append(d)
                 emit(lambda s, d=d: L.rho_conv_nd_fwd(C.byref(d), s), "dgrad",
                      flops=2.0 * (dact.numel() // cin) * cin * cw.cout * cw.taps, nbytes=float(esz) * (dY.numel() + dact.numel()))
                 if pre is not None:
@@ -732,6 +775,7 @@ class _Plan:
                                        res=g1 if acc1 else None, res2=g2 if (x2 is not None and acc2) else None,
                                        zs_hw=zs, out_hw=(x1.shape[2], x1.shape[3]) if zs != (0, 0) else (0, 0), **common)
                 self.keep.append(d)
+                self.fwd_descs.append(d)
                 emit(lambda s, d=d: L.rho_conv_nd_fwd(C.byref(d), s), "dgrad",
                      flops=2.0 * (x1.numel() // c1) * cin * cw.cout * cw.taps, nbytes=float(esz) * (dY.numel() + x1.numel()))
                 written.add(key(x1))
@@ -814,20 +858,21 @@ class _Plan:
         self.bwd_marks.append((len(bw), emb_params))
         self.pool_bytes = sum(t.numel() * t.element_size() for t in pool.all)
 
+    def variants(self) -> List[str]:
+        """Names of the k_conv / k_wgrad instantiations this plan launches (rho_conv_variant / rho_conv_wgrad_variant)."""
+        out = [ops.conv_variant(d) for d in self.fwd_descs]
+        out += [ops.conv_wgrad_variant(d, w_) for d, w_ in self.wgrad_descs]
+        return out
+
     # ------------------------------------------------------------------ execution
     def run(self, x: Tensor, timesteps: Optional[Tensor], y: Optional[Tensor], t_scalar_dev: Optional[Tensor]) -> Tensor:
         eng = self.eng
         m = eng.model
         if x.data_ptr() != self.x_in.data_ptr():
             self.x_in.copy_(x)
-        # timestep embedding rows (interleaved sin/cos), gathered on the device
-        if t_scalar_dev is not None:
-            ops.embed_gather(eng.sin_table(1024), None, self.B, t_scalar_dev, out=self.sin_in)
-        else:
-            hip.require_gpu(timesteps, "timesteps")
-            ts = timesteps.to(torch.int64).contiguous()
-            ops.embed_gather(eng.sin_table(1024), ts, self.B, out=self.sin_in)
+        te0, te2 = m.time_embed[0], m.time_embed[2]
         self.cond_src = None
+        self.cond_dev = None
         if self.cond is not None:
             # label handling of unet_v2.py:702-719
             if y.dim() == 2 and tuple(y.shape) == tuple(self.emb.shape):
@@ -837,10 +882,32 @@ class _Plan:
                     assert y.shape == (x.shape[0],)
                 else:
                     assert y.shape[0] == self.emb.shape[0]
-                with (torch.enable_grad() if self.train else torch.no_grad()):
-                    c = m.cond_fn(y)          # a few embedding lookups on [B, k] labels (host-logic sized)
-                self.cond_src = c if (self.train and c.requires_grad) else None
-                self.cond.copy_(c.detach())
+                cd = eng.cond_device_tables()
+                if cd is not None:
+                    # MultiEmbeddings on the device: category lookup by exact equality + row sum, no host synchronisation
+                    yf = y.to(device=self.cond.device, dtype=torch.float32).contiguous()
+                    if yf.dim() == 2 and yf.shape[1] != cd["nkeys"]:
+                        raise hip.RhoHipError(f"labels have {yf.shape[1]} columns, the parameter space has {cd['nkeys']} keys")
+                    self.keep_y = yf
+                    check(self.L.rho_multi_embed(ptr(yf), 1 if yf.dim() == 1 else yf.shape[1], ptr(cd["space"]), ptr(cd["key_off"]),
+                                                 ptr(cd["tables"]), cd["nkeys"], self.B, self.cond.shape[1], ptr(self.cond),
+                                                 ptr(self.cond_idx), ptr(eng.err_flag()), hip.stream()), "rho_multi_embed")
+                    self.cond_dev = cd
+                else:
+                    with (torch.enable_grad() if self.train else torch.no_grad()):
+                        c = m.cond_fn(y)          # a user-supplied cond_fn module (not MultiEmbeddings): evaluated as given
+                    self.cond_src = c if (self.train and c.requires_grad) else None
+                    self.cond.copy_(c.detach())
+        # timestep embedding: sinusoid of t (any integer) -> Linear -> SiLU -> Linear (+ cond), one launch
+        if t_scalar_dev is not None:
+            tptr, tsptr = None, ptr(t_scalar_dev)
+        else:
+            hip.require_gpu(timesteps, "timesteps")
+            self.t_in.copy_(timesteps.reshape(-1))
+            tptr, tsptr = ptr(self.t_in), None
+        check(self.L.rho_timestep_embed(ptr(eng.omega()), tptr, tsptr, ptr(te0.weight), ptr(te0.bias), ptr(te2.weight), ptr(te2.bias),
+                                        ptr(self.cond), ptr(self.sin_in), ptr(self.emb_h), ptr(self.emb), self.B, eng.mc,
+                                        self.emb.shape[1], hip.stream()), "rho_timestep_embed")
         s = hip.stream()
         for op in self.ops:
             rc = op(s)
@@ -862,9 +929,18 @@ class _Plan:
                 check(rc, "UNet backward plan launch")
             if on_ready is not None and (i + 1) in marks:
                 on_ready(marks[i + 1])
-        if self.cond_src is not None:
+        if self.cond_dev is not None:
+            cd = self.cond_dev
+            gsig = tuple(w.grad.data_ptr() for w in cd["weights"])
+            if getattr(self, "_gp_sig", None) != gsig:              # gradient storage is stable under the arena optimizer
+                self._gp = torch.tensor(list(gsig), dtype=torch.int64, device=self.demb.device)
+                self._gp_sig = gsig
+            gp = self._gp
+            check(self.L.rho_multi_embed_bwd(ptr(self.demb), ptr(self.cond_idx), ptr(gp), cd["nkeys"], self.B, self.demb.shape[1], s),
+                  "rho_multi_embed_bwd")
+        elif self.cond_src is not None:
             with torch.enable_grad():
-                self.cond_src.backward(self.demb)      # MultiEmbeddings tables (tiny scatter-add)
+                self.cond_src.backward(self.demb)      # a user-supplied cond_fn module
         if on_ready is not None:
             on_ready([])
 

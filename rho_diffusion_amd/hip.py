@@ -12,7 +12,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librho_hip.so")
+# RHO_HIP_LIB: load an alternative build of the library (same-box A/B measurements) without touching the in-tree one
+LIB_PATH = os.environ.get("RHO_HIP_LIB") or os.path.join(_HERE, "librho_hip.so")
 
 RHO_F32 = 0
 RHO_BF16 = 1
@@ -39,13 +40,19 @@ class ConvDesc(C.Structure):
 SIGNATURES = {
     "rho_abi_version": (c_int, []),
     "rho_build_info": (C.c_char_p, []),
-    "rho_q_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "rho_q_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "rho_p_sample_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "rho_step_advance": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p]),
     "rho_philox_normal": (c_int, [c_void_p, c_int64, c_uint64, c_uint64, c_void_p, c_void_p]),
     "rho_mse": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "rho_adamw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int32, c_void_p]),
-    "rho_embed_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "rho_timestep_embed": (c_int, [c_void_p] * 11 + [c_int64, c_int64, c_int64, c_void_p]),
+    "rho_multi_embed": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                c_void_p]),
+    "rho_multi_embed_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "rho_randint": (c_int, [c_void_p, c_int64, c_int64, c_uint64, c_uint64, c_void_p, c_void_p]),
+    "rho_sph_harm_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "rho_sph_harm_fields": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rho_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
     "rho_pack_input": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     "rho_prep_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
@@ -55,6 +62,8 @@ SIGNATURES = {
                                 c_void_p, c_void_p, c_void_p, c_void_p]),
     "rho_conv_nd_fwd": (c_int, [C.POINTER(ConvDesc), c_void_p]),
     "rho_conv_stats_tiles": (c_int64, [C.POINTER(ConvDesc)]),
+    "rho_conv_variant": (c_int, [C.POINTER(ConvDesc), C.c_char_p, c_int]),
+    "rho_conv_wgrad_variant": (c_int, [C.POINTER(ConvDesc), c_int64, C.c_char_p, c_int]),
     "rho_gn_finalize2": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rho_im2col_taps": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int64, c_void_p]),
@@ -78,7 +87,8 @@ SIGNATURES = {
     "rho_ema_update": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
     "rho_abs_quantile_workspace_bytes": (c_int64, [c_int64]),
     "rho_abs_quantile": (c_int, [c_void_p, c_int64, c_int64, c_double, c_void_p, c_void_p, c_void_p]),
-    "rho_q_sample_coef": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "rho_q_sample_coef": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p,
+                                  c_void_p]),
     "rho_ddim_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_float,
                               c_float, c_float, c_float, c_void_p]),
     "rho_chan_sum": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p]),

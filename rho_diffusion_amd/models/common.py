@@ -1,4 +1,7 @@
-"""Timestep embedding (reference: rho_diffusion/models/common.py:27-80)."""
+"""Timestep embedding layer of the registry (reference: rho_diffusion/models/common.py:27-80).
+
+The sinusoid is evaluated by the HIP kernel ``rho_timestep_embed`` for any integer t (GPU tensors only: the product path has
+no CPU fallback); the UNet engine calls the same kernel fused with the two ``time_embed`` linears."""
 from __future__ import annotations
 
 import torch
@@ -8,17 +11,12 @@ from ..registry import registry
 
 
 def sinosoidal_position_embedding(t: torch.Tensor, dim: int, wavelength: int = 10000) -> torch.Tensor:
-    """Interleaved [sin(t/w_0), cos(t/w_0), sin(t/w_1), ...], always float32 (common.py:27-43).
-    Host-side table builder: the UNet engine evaluates it once for t = 0..T-1 and gathers rows on
-    the device (rho_embed_gather)."""
-    assert dim % 2 == 0, "`dim` should be dividable by 2."
-    device = t.device
-    i = torch.arange(dim // 2, device=device)
-    omega = torch.pow(wavelength, 2 * i / dim)
-    pe = torch.empty(len(t), dim, device=device)
-    pe[:, 2 * i] = torch.sin(t[:, None] / omega[None, :]).float()
-    pe[:, 2 * i + 1] = torch.cos(t[:, None] / omega[None, :]).float()
-    return pe
+    """float32 [len(t), dim] with columns (sin(t / w_0), cos(t / w_0), sin(t / w_1), ...), w_i = wavelength^(2i / dim)."""
+    from .. import hip
+    from ..engine import ops
+    hip.require_gpu(t, "t")
+    tt = t.reshape(-1).to(torch.int64).contiguous()
+    return ops.timestep_embed(ops.sinusoid_frequencies(dim, wavelength, t.device), tt, tt.numel())
 
 
 @registry.register_layer("SinusoidalPositionEmbedding")

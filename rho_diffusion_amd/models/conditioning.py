@@ -15,9 +15,9 @@ class MultiEmbeddings(nn.Module):
     """Sum over parameter-space keys of an ``nn.Embedding`` lookup, the category being the position
     of the label value in ``parameter_space[key]`` (exact float equality, conditioning.py:132).
 
-    The lookup indices are resolved with a handful of tiny integer ops on the label tensor's
-    device; the embedding rows are summed by the same ops.  ([B, k] labels, k <= a few keys:
-    host-logic sized, not a kernel target - SURVEY 8a row a19.)"""
+    Inside the UNet engine the lookup runs on the device (``rho_multi_embed``: category resolution + row sum in one launch,
+    no host synchronisation; backward ``rho_multi_embed_bwd``).  ``forward`` below is the stand-alone module call for GPU
+    label tensors and uses the same kernel; the module only holds the tables."""
 
     def __init__(self, parameter_space=None, embedding_dim: int = 512, parameter_space_dim: int = 3,
                  embedding_size: Union[int, list, dict, OrderedDict] = None) -> None:
@@ -40,11 +40,27 @@ class MultiEmbeddings(nn.Module):
                     self.embedding_layers[key] = nn.Embedding(value, embedding_dim)
 
     def forward(self, y: torch.Tensor) -> torch.Tensor:
-        emb = None
-        for i, (key, layer) in enumerate(self.embedding_layers.items()):
-            yi = y if y.dim() == 1 else y[:, i]
-            space = torch.tensor(self.parameter_space[key], device=y.device)
-            categorical = torch.where(yi[:, None] == space[None, :])[1]
-            e = layer(categorical)
-            emb = e if emb is None else emb + e
-        return emb
+        if len(self.embedding_layers) == 0:
+            return None                                      # conditioning.py:117,139
+        from .. import hip
+        from ..hip import check, ptr
+        hip.require_gpu(y, "y")
+        keys = list(self.embedding_layers.keys())
+        weights = [self.embedding_layers[k].weight for k in keys]
+        dev = y.device
+        vals = [torch.tensor(self.parameter_space[k]).to(torch.float32) for k in keys]
+        off = [0]
+        for v in vals:
+            off.append(off[-1] + v.numel())
+        space = torch.cat(vals).to(dev)
+        key_off = torch.tensor(off, dtype=torch.int32, device=dev)
+        tables = torch.tensor([w.data_ptr() for w in weights], dtype=torch.int64, device=dev)
+        yf = y.to(torch.float32).contiguous()
+        B = yf.shape[0]
+        out = torch.empty(B, self.embedding_dim, dtype=torch.float32, device=dev)
+        err = torch.zeros(1, dtype=torch.int32, device=dev)
+        check(hip.lib().rho_multi_embed(ptr(yf), 1 if yf.dim() == 1 else yf.shape[1], ptr(space), ptr(key_off), ptr(tables), len(keys), B,
+                                        self.embedding_dim, ptr(out), None, ptr(err), hip.stream()), "rho_multi_embed")
+        if int(err.item()) & 2:                              # stand-alone call: fail as the reference does on an unknown label
+            raise IndexError("MultiEmbeddings: a label value is not in the parameter space")
+        return out

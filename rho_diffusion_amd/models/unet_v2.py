@@ -243,6 +243,25 @@ class UNet(nn.Module):
         self._engines = {}
 
     # ------------------------------------------------------------------ HIP engine plumbing
+    def __deepcopy__(self, memo):
+        """Copies (EMA shadow models, DDP replicas) carry parameters and configuration only: engines hold plans keyed by the
+        identity of THIS module tree, ctypes descriptors and raw device pointers, and are rebuilt by the copy on first use."""
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k in ("_engines", "grad_hooks"):
+                continue
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        new.__dict__["_engines"] = {}
+        return new
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_engines"] = {}
+        state.pop("grad_hooks", None)
+        return state
+
     def engine(self, dtype: Optional[torch.dtype] = None):
         from ..engine.unet_engine import UNetEngine
         dtype = dtype or self.compute_dtype

@@ -18,7 +18,8 @@ def _declared():
 def test_header_declares_the_expected_surface():
     names = _declared()
     for must in ["rho_q_sample", "rho_p_sample_step", "rho_philox_normal", "rho_conv_nd_fwd", "rho_attention_fwd",
-                 "rho_gn_partial", "rho_gn_finalize", "rho_adamw", "rho_mse", "rho_linear", "rho_embed_gather"]:
+                 "rho_gn_partial", "rho_gn_finalize", "rho_adamw", "rho_mse", "rho_linear", "rho_timestep_embed", "rho_multi_embed",
+                 "rho_randint", "rho_sph_harm_fields", "rho_conv_variant"]:
         assert must in names
 
 

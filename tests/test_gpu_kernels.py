@@ -109,14 +109,43 @@ def test_adamw_matches_golden(ops):
         assert rel_l2(p, torch.from_numpy(g[f"p{step}"])) < 1e-6
 
 
-def test_embed_and_linear(ops):
-    tab = R.sinusoidal_embedding(torch.arange(1000), 64)
-    t = torch.tensor([0, 1, 17, 500, 999])
-    out = ops.embed_gather(tab.to(DEV), t.to(DEV), 5)
-    assert torch.equal(out.cpu(), tab[t])
-    ts = torch.tensor([17], dtype=torch.int32, device=DEV)
-    out = ops.embed_gather(tab.to(DEV), None, 3, t_scalar_dev=ts)
-    assert torch.equal(out.cpu(), tab[17].expand(3, -1))
+def test_timestep_sinusoid_any_t(ops):
+    """rho_timestep_embed without the MLP: the interleaved sinusoid for ANY integer t (the r1 engine gathered rows of a
+    1024-row table and clamped later steps to t = 1023), vs the oracle and the reference-minted golden g2."""
+    g = load_golden("g2_sinusoid.npz")
+    tg = torch.from_numpy(g["t"])
+    for dim in (32, 64, 128):
+        om = ops.sinusoid_frequencies(dim, 10000, DEV)
+        out = ops.timestep_embed(om, tg.to(DEV), len(tg))
+        # sinf / cosf of the device libm vs the host's: a couple of ulp of the result, measured against |value| <= 1
+        assert float((out.cpu() - torch.from_numpy(g[f"dim{dim}"])).abs().max()) < 5e-7
+    t = torch.tensor([0, 1, 17, 500, 999, 1023, 1024, 1999, 2000, 3999, 100000])
+    ref = R.sinusoidal_embedding(t, 64)
+    out = ops.timestep_embed(ops.sinusoid_frequencies(64, 10000, DEV), t.to(DEV), len(t))
+    assert float((out.cpu() - ref).abs().max()) < 5e-7
+    assert float((out.cpu()[6] - out.cpu()[5]).abs().max()) > 1e-3        # t = 1024 is not t = 1023
+    ts = torch.tensor([1999], dtype=torch.int32, device=DEV)
+    out = ops.timestep_embed(ops.sinusoid_frequencies(64, 10000, DEV), None, 3, t_scalar_dev=ts)
+    assert float((out.cpu() - ref[7].expand(3, -1)).abs().max()) < 5e-7
+
+
+def test_timestep_embed_mlp_and_linear(ops):
+    """Fused sinusoid -> Linear -> SiLU -> Linear (+ cond) vs the oracle's embedding chain (unet_v2.py:699-719)."""
+    mc, E, B = 64, 256, 5
+    sd = {"time_embed.0.weight": det_normal((E, mc), "tw0") / 8, "time_embed.0.bias": det_normal((E,), "tb0") * 0.1,
+          "time_embed.2.weight": det_normal((E, E), "tw2") / 16, "time_embed.2.bias": det_normal((E,), "tb2") * 0.1}
+    t = torch.tensor([0, 3, 999, 1500, 2000])
+    cond = det_normal((B, E), "tcond")
+    ref = R.unet_embedding(sd, dict(model_channels=mc, num_classes=1), t, cond)
+    g = {k: v.to(DEV) for k, v in sd.items()}
+    pe = torch.empty(B, mc, device=DEV)
+    h = torch.empty(B, E, device=DEV)
+    out = ops.timestep_embed(ops.sinusoid_frequencies(mc, 10000, DEV), t.to(DEV), B, w0=g["time_embed.0.weight"],
+                             b0=g["time_embed.0.bias"], w2=g["time_embed.2.weight"], b2=g["time_embed.2.bias"], cond=cond.to(DEV),
+                             pe_out=pe, h_out=h)
+    assert rel_l2(out, ref) < 2e-6
+    assert rel_l2(pe, R.sinusoidal_embedding(t, mc)) < 1e-6
+    assert rel_l2(h, F.linear(R.sinusoidal_embedding(t, mc), sd["time_embed.0.weight"], sd["time_embed.0.bias"])) < 2e-6
     for (B, K, O, ai, ao) in [(5, 64, 256, False, True), (5, 256, 1000, True, False), (3, 1024, 130, False, False)]:
         x = det_normal((B, K), "lx")
         w = det_normal((O, K), "lw") / math.sqrt(K)

@@ -214,8 +214,10 @@ def test_g14_spherical_harmonic_fields():
         parts = key.split("/")
         G = int(parts[0][1:])
         l, m = (int(v[1:]) for v in parts[1].split("_"))
+        if parts[2] == "minmax":
+            continue
         f = R.spherical_harmonic_field(l, m, G)[0].numpy()
-        if len(parts) == 2:
+        if parts[2] == "full":
             np.testing.assert_allclose(f, g[key], rtol=0, atol=2e-7)
         elif parts[2] == "sub":
             np.testing.assert_allclose(f[::4, ::4, ::4], g[key], rtol=0, atol=2e-7)
@@ -225,7 +227,7 @@ def test_g14_spherical_harmonic_fields():
             mom = np.array([f.astype(np.float64).sum(), (f.astype(np.float64) ** 2).sum(), f.min(), f.max()])
             np.testing.assert_allclose(mom, g[key], rtol=1e-6)
         seen += 1
-    assert seen >= 11 + 12
+    assert seen >= 24 + 12
 
 
 GD_TABLES = ("betas", "alphas_cumprod", "alphas_cumprod_prev", "alphas_cumprod_next", "sqrt_alphas_cumprod",
