@@ -73,6 +73,8 @@ LAYER_CASES = [
     ("c2_up256", F32, 2, 256, 0, 256, (32, 32), 3, 1, True, False, False, None),
     ("c2_qkv512", F32, 2, 512, 0, 1536, (16, 16), 1, 1, False, True, False, 1024),
     ("c2_head", F32, 2, 64, 0, 1, (128, 128), 3, 1, False, True, False, 0),
+    ("c2_down64", F32, 2, 64, 0, 64, (128, 128), 3, 2, False, False, False, None),
+    ("c2_skip128_64", F32, 2, 128, 64, 64, (128, 128), 1, 1, False, False, False, None),
 ]
 _IDS = [c[0] for c in LAYER_CASES]
 _SEEN = {}          # case name -> set of variant names its launches used (filled by the parity test)
@@ -310,7 +312,9 @@ def test_attention_forward_and_backward_at_bench_length(ops, heads, ch, T):
     dk = g[:, C:2 * C].reshape(B * heads, ch, T)
     dv = g[:, 2 * C:].reshape(B * heads, ch, T)
     assert rel_l2(dq[:, :, rows], qg.grad[:, :, rows]) < 2e-2, ("dq", rel_l2(dq[:, :, rows], qg.grad[:, :, rows]))
-    assert float(dq.abs().sum() - dq[:, :, rows].abs().sum()) == 0.0       # queries outside the slice get exactly zero
+    outside = torch.ones(T, dtype=torch.bool)
+    outside[rows] = False
+    assert float(dq[:, :, outside].abs().max()) == 0.0                     # queries outside the slice get exactly zero
     assert rel_l2(dk, kg.grad) < 2e-2, ("dk", rel_l2(dk, kg.grad))
     assert rel_l2(dv, vg.grad) < 2e-2, ("dv", rel_l2(dv, vg.grad))
 

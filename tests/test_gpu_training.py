@@ -3,14 +3,14 @@ produced by the real reference (tests/golden/g4_unet.npz, g5_ddpm.npz: per param
 first 6 values]), plus the fused AdamW step.
 
 Tolerances: fp32 engine: per-parameter gradient norm within 2e-3 relative (+1e-6 abs), leading values
-within 2e-3 of the tensor's rms scale; bf16 engine: global gradient-norm agreement within 5 % and per-parameter
-norms within 15 % for all but a few tiny tensors (bf16 activations/gradients, fp32 accumulation)."""
+within 2e-3 of the tensor's rms scale; bf16 engine: per-parameter cosine >= 0.99 against the oracle's full gradient
+vector and norm within 5 %, for every parameter (bf16 activations/gradients, fp32 accumulation)."""
 import numpy as np
 import pytest
 import torch
 from torch import nn
 
-from helpers import (PARAM_SPACE, UNET_CASES, case_inputs, det_normal, det_state_dict, det_uniform, golden_template,
+from helpers import (PARAM_SPACE, UNET_CASES, case_inputs, cosine, det_normal, det_state_dict, det_uniform, golden_template,
                      grad_digest_of, load_golden, rel_l2)
 from gpu_util import DEV
 
@@ -63,26 +63,38 @@ def test_unet_backward_fp32_vs_reference_golden(case):
     assert not bad, bad[:6]
 
 
-@pytest.mark.parametrize("case", ["tiny2d", "tiny3d", "reftest2d", "full3d", "tiny2d_multi"])
+@pytest.mark.parametrize("case", list(UNET_CASES.keys()))
 def test_unet_backward_bf16_tracks_reference(case):
+    """bf16 engine (c3 trains in bf16): every parameter's gradient must point where the reference's does - cosine >= 0.99
+    against the oracle's full gradient vector (the oracle is pinned to the reference by the g4 digests) - and have its norm
+    within 5 %; no free outliers.  Parameters whose reference gradient is numerically zero (below 1e-5 of the global gradient
+    norm: e.g. the key bias of an attention block, softmax is shift-invariant) are checked by magnitude instead."""
+    from oracle import ref_torch as R
     g, model, loss = _run_case(case, torch.bfloat16)
     assert abs(loss.item() - float(g[f"{case}/loss"])) < 5e-2
-    tot_ref = tot = 0.0
-    worse = 0
+    cfg, x, t, y = case_inputs(case)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in det_state_dict(golden_template(g, case), case).items()}
+    pred = R.unet_forward(sdg, cfg, x, t, y, PARAM_SPACE)
+    torch.nn.functional.mse_loss(pred, det_normal(tuple(pred.shape), case + "tgt")).backward()
+    gtot = float(np.sqrt(sum(float(v.grad.double().norm()) ** 2 for v in sdg.values() if v.grad is not None)))
+    bad = []
     n = 0
     for name, p in model.named_parameters():
-        key = f"{case}/grad/{name}"
-        if key not in g.files:
+        ref = sdg[name].grad
+        if ref is None:
             continue
-        ref = g[key]
-        d = grad_digest_of(p.grad)
-        tot_ref += ref[0] ** 2
-        tot += d[0] ** 2
         n += 1
-        if abs(d[0] - ref[0]) > 0.15 * ref[0] + 1e-5:
-            worse += 1
-    assert abs(np.sqrt(tot) - np.sqrt(tot_ref)) < 0.05 * np.sqrt(tot_ref)
-    assert worse <= max(3, n // 10), (worse, n)
+        rn, dn = float(ref.double().norm()), float(p.grad.double().norm())
+        assert abs(rn - g[f"{case}/grad/{name}"][0]) <= 1e-4 * rn + 1e-6            # the oracle IS the reference here
+        if rn < 1e-5 * gtot:
+            if dn > 1e-3 * gtot:
+                bad.append((name, "should be ~0", dn, rn))
+            continue
+        c = cosine(p.grad, ref)
+        if c < 0.99 or abs(dn - rn) > 0.05 * rn:
+            bad.append((name, round(c, 4), round(dn / rn, 4)))
+    assert n > 20
+    assert not bad, bad[:8]
 
 
 @pytest.mark.parametrize("T", [50, 100])
