@@ -14,8 +14,10 @@ import torch
 
 from . import hip
 from .engine import ops
+from .registry import registry
+from .utils import calculate_sha512_embedding
 
-__all__ = ["spherical_harmonic_fields", "spherical_harmonic_field", "SphericalHarmonicPool"]
+__all__ = ["spherical_harmonic_fields", "spherical_harmonic_field", "SphericalHarmonicPool", "SphericalHarmonicDataset"]
 
 
 def spherical_harmonic_fields(lm: Sequence[Tuple[int, int]], grid: int, dims: int = 3, device="cuda") -> torch.Tensor:
@@ -57,3 +59,56 @@ class SphericalHarmonicPool:
         idx = torch.arange(batch_size, device=self.fields.device) % len(self.fields)
         out = self.fields[idx].contiguous()
         return out.to(device) if device is not None else out
+
+
+@registry.register_dataset("SphericalHarmonicDataset")
+class SphericalHarmonicDataset(torch.utils.data.Dataset):
+    """The reference's synthetic dataset (data/synthetic.py:127-305) with the fields generated on the device: item = (density
+    float32 ``[1, G, G, G]`` on the GPU, label embedding = the 256-entry sha512 embedding of ``{"l": l, "m": m}``,
+    synthetic.py:299-304).  (l, m) are drawn per item with ``random.randint`` exactly as ``random_set`` does (:240-254; the
+    builtin RNG is seeded in the constructor like the reference's ``random_seed`` setter).  ``batch(B)`` draws B items with
+    ONE generator launch - what a training loop on this engine should call.  HDF5 replay (``h5_path``) is not built.
+    ``parameter_space`` is None, as in the reference (its constructor only binds a local)."""
+    parameter_space = None
+
+    def __init__(self, max_l, h5_path=None, length: int = 1000, random_seed=None, use_emb_as_labels: bool = True, device="cuda",
+                 **grid_kwargs):
+        if h5_path is not None:
+            raise NotImplementedError("HDF5 replay is outside the hot path (SURVEY 8f row 3); fields are generated on the device")
+        if isinstance(max_l, int):
+            assert max_l > 0, f"Invalid maximum value of l > 0: {max_l}"
+        self.max_l = max_l
+        self.length = length
+        self.use_emb_as_labels = use_emb_as_labels
+        self.device = device
+        self.grid_el = int(grid_kwargs.get("grid_el", 32))
+        if not random_seed:
+            import os
+            random_seed = int(os.environ.get("PL_GLOBAL_SEED", 1616))
+        self.random_seed = random_seed
+        random.seed(random_seed)
+        self.labels_emb_map = dict()
+
+    @property
+    def random_set(self) -> Tuple[int, int]:
+        l = random.randint(0, self.max_l)
+        return (l, random.randint(-l, l))
+
+    def __len__(self) -> int:
+        return self.length
+
+    def _label(self, l: int, m: int) -> torch.Tensor:
+        c = {"l": l, "m": m}
+        emb = calculate_sha512_embedding(c, l=256)
+        self.labels_emb_map[emb] = c
+        return emb
+
+    def __getitem__(self, index: int):
+        l, m = self.random_set
+        return spherical_harmonic_field(l, m, self.grid_el, 3, self.device), self._label(l, m)
+
+    def batch(self, batch_size: int):
+        lm = [self.random_set for _ in range(batch_size)]
+        data = spherical_harmonic_fields(lm, self.grid_el, 3, self.device)
+        labels = torch.stack([self._label(l, m) for l, m in lm]).to(data.device)
+        return data, labels

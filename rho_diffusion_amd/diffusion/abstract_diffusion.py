@@ -159,5 +159,7 @@ class AbstractDiffusionPipeline(_Base):
 
     @staticmethod
     def make_image_grid(batched_image, filename: str = None):
-        """Image-grid logging (abstract_diffusion.py:240-276) is plotting: out of scope (SURVEY 2.1 #2)."""
-        return None
+        """The reference tiles the batch into one image with torchvision and optionally saves a PNG
+        (abstract_diffusion.py:240-276).  Plotting is out of scope: the samples are handed back as they are,
+        so callers that do ``generate(...).cpu().numpy()`` (scripts/inference.py:166-169) keep working."""
+        return batched_image

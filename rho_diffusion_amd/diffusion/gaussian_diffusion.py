@@ -212,22 +212,26 @@ class GaussianDiffusionPipeline(AbstractDiffusionPipeline):
 
     # ------------------------------------------------------------------ wrappers
     def generate(self, parameter_space=None, random=False, save_figure_as=None):
-        """:1102-1146 without the figure: zero template of the last training shape (or 64^2), conditions from the
-        discrete parameter space, reverse_process."""
+        """:1102-1146: zero template of the last training batch shape, else ``[sampling_batch_size, out_channels] + data_shape``
+        from the backbone kwargs; labels = rows of the discrete parameter space (``sample_parameter_space`` by default);
+        reverse_process.  Returns what ``make_image_grid`` returns: the denoised samples (no figure is drawn)."""
         if hasattr(self, "data_shape"):
             shape = [int(x) for x in self.data_shape]
             shape[0] = self.sampling_batch_size
         else:
-            shape = [self.sampling_batch_size, self.backbone.out_channels, 64, 64]
+            shape = [self.sampling_batch_size, self.backbone_kwargs["out_channels"]] + list(self.backbone_kwargs["data_shape"])
+            self.data_dtype = torch.float32
         dev = next(self.backbone.parameters()).device
+        if parameter_space is None:
+            parameter_space = self.sample_parameter_space
+        conditions = None
         if parameter_space is not None:
-            conditions = sample_from_discrete_parameter_space(parameter_space, shape[0], random=random).to(dev)
-        else:
-            conditions = None
-        x_T = torch.zeros(shape, device=dev)
+            conditions = sample_from_discrete_parameter_space(parameter_space, shape[0], random=random, device=dev)
+        x_T = torch.zeros(shape, dtype=getattr(self, "data_dtype", torch.float32), device=dev)
         res = self.reverse_process(x_T, conditions=conditions, t_checkpoints=self.t_checkpoints)
         res["conditions"] = conditions
-        return res
+        self.last_samples = res
+        return self.make_image_grid(res["denoised"], filename=save_figure_as)
 
     def save_model_weights(self):
         save_model_checkpoint(self.backbone, "model.pth")

@@ -19,7 +19,14 @@ from torch import nn
 
 
 class GradBucketReducer:
-    def __init__(self, params_in_order: Sequence[nn.Parameter], bucket_bytes: int = 64 << 20, group=None):
+    def __init__(self, params_in_order: Sequence[nn.Parameter], bucket_bytes: int = 64 << 20, group=None,
+                 comm_dtype: torch.dtype = torch.float32):
+        """``comm_dtype=torch.bfloat16`` sends the buckets as bf16 (334 instead of 667 MB per step at 3-D mc = 64):
+        one cast pass per bucket on each side of the collective, the mean is rounded to bf16 once; fp32 gradients stay the
+        optimizer's input.  Default float32 = the reference's DDP numerics."""
+        if comm_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("comm_dtype must be float32 or bfloat16")
+        self.comm_dtype = comm_dtype
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # RCCL averages in the collective itself; gloo (CPU tests) has no AVG: sum, then scale
@@ -83,11 +90,14 @@ class GradBucketReducer:
         idxs = self.buckets[b]
         self.launched[b] = True
         flat = self._flat_view(idxs)
-        if flat is not None:
+        if flat is not None and self.comm_dtype == torch.float32:
             self.works.append((dist.all_reduce(flat, op=self._op(), group=self.group, async_op=True), flat, None))
+        elif flat is not None:
+            packed = flat.to(self.comm_dtype)                    # one cast pass; the fp32 arena view receives the mean in finish()
+            self.works.append((dist.all_reduce(packed, op=self._op(), group=self.group, async_op=True), packed, [flat]))
         else:
             gs = [self.params[i].grad for i in idxs]
-            packed = torch.cat([g.reshape(-1) for g in gs])      # copy-in / copy-out fallback (no arena)
+            packed = torch.cat([g.reshape(-1) for g in gs]).to(self.comm_dtype)      # copy-in / copy-out fallback (no arena)
             self.works.append((dist.all_reduce(packed, op=self._op(), group=self.group, async_op=True), packed, gs))
 
     def _op(self):

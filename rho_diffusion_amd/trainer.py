@@ -16,7 +16,8 @@ from .parallel import GradBucketReducer, broadcast_parameters
 
 
 class DPTrainer:
-    def __init__(self, ddpm, lr: Optional[float] = None, bucket_bytes: int = 64 << 20, scale_lr_by_sqrt_world: bool = True):
+    def __init__(self, ddpm, lr: Optional[float] = None, bucket_bytes: int = 64 << 20, scale_lr_by_sqrt_world: bool = True,
+                 comm_dtype: torch.dtype = torch.float32, device_timesteps: bool = True):
         self.ddpm = ddpm
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         broadcast_parameters(ddpm)
@@ -31,7 +32,9 @@ class DPTrainer:
         self.opt = HipAdamW(ddpm.parameters(), arena_order=order,
                             **{k: v for k, v in kw.items() if k in ("lr", "betas", "eps", "weight_decay")})
         self.opt.build_arena()                           # re-homes parameters and gradients into flat arenas
-        self.reducer = GradBucketReducer(order, bucket_bytes=bucket_bytes)
+        self.reducer = GradBucketReducer(order, bucket_bytes=bucket_bytes, comm_dtype=comm_dtype)
+        if device_timesteps and hasattr(ddpm, "device_timesteps"):
+            ddpm.device_timesteps = True                 # t drawn by rho_randint: no CPU randint + H2D copy per step
         ddpm.backbone.grad_hooks = self.reducer
         ddpm.train()
 

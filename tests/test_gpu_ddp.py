@@ -65,6 +65,36 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _collect(procs, q, n, timeout=300):
+    """n results from the workers' queue; a worker that dies fails the test at once, and no child outlives the test
+    (a surviving rank would sit in a collective holding the GPU)."""
+    import queue
+    import time
+    out = []
+    try:
+        deadline = time.time() + timeout
+        while len(out) < n:
+            try:
+                out.append(q.get(timeout=1.0))
+            except queue.Empty:
+                dead = [p for p in procs if p.exitcode not in (None, 0)]
+                assert not dead, f"worker exited with {[p.exitcode for p in dead]}"
+                assert time.time() < deadline, "timed out waiting for the workers"
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+        return out
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        for p in procs:
+            p.join(10)
+            if p.is_alive():
+                p.kill()
+                p.join(10)
+
+
 def test_dp_trainer_two_ranks_match_single_process():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -72,13 +102,7 @@ def test_dp_trainer_two_ranks_match_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = {}
-    for _ in range(2):
-        r, flat = q.get(timeout=300)
-        got[r] = torch.from_numpy(flat)
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    got = {r: torch.from_numpy(flat) for r, flat in _collect(procs, q, 2)}
     assert torch.equal(got[0], got[1])                     # replicas identical after 2 steps
 
     # single process: same two "rank" batches per step, gradients averaged by hand, same fused AdamW
@@ -139,6 +163,60 @@ def test_rccl_backend_bucketed_all_reduce_single_rank():
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_single_rank, args=(_free_port(), q))
     p.start()
-    status, nb = q.get(timeout=300)
-    p.join(120)
+    (status, nb), = _collect([p], q, 1)
     assert status == "ok" and nb >= 2 and p.exitcode == 0
+
+
+def test_all_reduce_is_issued_while_backward_is_still_running(monkeypatch):
+    """'RCCL all-reduce overlapped with backward'.  With a recording stand-in for dist.all_reduce, the first bucket's
+    collective must be issued BEFORE the last weight-gradient kernel of the backward plan is launched (i.e. from an on_ready
+    mark inside run_backward, not from finish()), buckets must go out in tail-to-head order of the arena, every bucket exactly
+    once, and all of them be flat arena views (zero-copy).  Also the bf16-bucket option: half the bytes, fp32 gradients restored."""
+    import torch.distributed as dist
+    from helpers import det_uniform
+    from rho_diffusion_amd import parallel
+    from rho_diffusion_amd.trainer import DPTrainer
+    for comm_dtype in (torch.float32, torch.bfloat16):
+        ddpm, xshape = _build()
+        trainer = DPTrainer(ddpm, bucket_bytes=400_000, comm_dtype=comm_dtype)
+        red = trainer.reducer
+        assert len(red.buckets) >= 3
+        x0 = det_uniform(xshape, "ovl_x", 0.0, 1.0).to("cuda")
+        trainer.step(x0)                                       # builds the training plan (world = 1: no collectives yet)
+        plan = ddpm.backbone.engine()._last_train_plan
+        events = []
+
+        class _Work:
+            def wait(self):
+                events.append(("wait",))
+
+        def fake_all_reduce(t, op=None, group=None, async_op=False):
+            events.append(("all_reduce", t.data_ptr(), t.numel(), t.dtype))
+            return _Work()
+
+        monkeypatch.setattr(parallel.dist, "all_reduce", fake_all_reduce)
+        red.world = 2                                          # arm the collective path on the single process
+        red.avg_in_collective = True
+        for i, (fn, info) in enumerate(zip(list(plan.bwd), plan.bwd_info)):
+            plan.bwd[i] = (lambda s, fn=fn, kind=info["kind"]: (events.append(("launch", kind)), fn(s))[1])
+        ref = None
+        if comm_dtype == torch.bfloat16:
+            ref = trainer.opt.flat_grads[0]
+        trainer.step(x0)
+        red.world = 1
+        monkeypatch.undo()
+        ar = [i for i, e in enumerate(events) if e[0] == "all_reduce"]
+        wg = [i for i, e in enumerate(events) if e == ("launch", "wgrad")]
+        assert len(ar) == len(red.buckets) and len(wg) > 10
+        assert ar[0] < wg[-1], "first bucket was not issued before the last wgrad launch"
+        assert sum(1 for i in ar if i < wg[-1]) >= len(red.buckets) - 2          # all but the head buckets go out under backward
+        if comm_dtype == torch.float32:
+            arena = trainer.opt.flat_grads[0]
+            ptrs = [events[i][1] for i in ar]
+            assert all(arena.data_ptr() <= p < arena.data_ptr() + 4 * arena.numel() for p in ptrs)       # zero-copy arena views
+            assert ptrs == sorted(ptrs, reverse=True)                                                     # tail of the arena first
+            assert sum(events[i][2] for i in ar) == arena.numel()
+        else:
+            assert all(events[i][3] == torch.bfloat16 for i in ar)
+            assert sum(events[i][2] for i in ar) == ref.numel()
+            assert torch.isfinite(ref).all() and float(ref.abs().sum()) > 0

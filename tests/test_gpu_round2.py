@@ -79,8 +79,9 @@ def test_generate_shapes_labels_and_values_vs_reference():
     gshape = tuple(int(v) for v in g["gen/shape"])
     tape = iter([det_normal(gshape, f"gentape_{i}").to(DEV) for i in range(T)])
     ddpm.noise = lambda data: next(tape).clone()
-    assert ddpm.generate() is None                              # make_image_grid is out of scope (plotting)
+    out = ddpm.generate()                                       # the samples themselves (no figure is drawn: plotting is out of scope)
     den = ddpm.last_samples["denoised"]
+    assert out is den
     assert tuple(den.shape) == gshape and ddpm.data_dtype == torch.float32
     assert rel_l2(den, torch.from_numpy(g["gen/denoised"])) < 2e-3
     # p_sample after a training step takes the batch shape of the data (ddpm.py:320-323)
@@ -325,3 +326,89 @@ def test_checkpoint_round_trip(tmp_path, monkeypatch):
         ddpm2.backbone.load_state_dict(torch.load(tmp_path / "model.pth"))
         again = ddpm2.backbone(x.to(DEV), t.to(DEV), y.to(DEV))
     assert not torch.equal(other, before) and torch.equal(again, before)
+
+
+# ----------------------------------------------------------------------------- x3: script-shaped drop-in flow
+def test_script_shaped_flow_config_registry_train_checkpoint_sample(tmp_path, monkeypatch):
+    """What scripts/training.py:70-158 and scripts/inference.py:109-169 do, written against the REFERENCE's module names
+    (``rho_diffusion`` aliased to this package): JSON config -> registry lookups -> DDPM -> 2 data-parallel trainer steps ->
+    model.pth -> a fresh GaussianDiffusionPipeline loads it -> generate() over the inference parameter space.  3-D 16^3."""
+    import json
+    import rho_diffusion_amd
+    rho_diffusion_amd.install_alias()
+    from rho_diffusion import diffusion                                   # noqa: E402  (the alias)
+    from rho_diffusion.config import ExperimentConfig
+    from rho_diffusion.registry import registry
+    from rho_diffusion.utils import sample_from_discrete_parameter_space
+    from rho_diffusion_amd.trainer import DPTrainer
+
+    space = {"l": [0, 1, 2, 3], "m": [-1.5, 0.5, 2.5]}
+    cfg = {
+        "experiment": "script_shaped",
+        "model": {"name": "UNetv2", "kwargs": {"dims": 3, "in_channels": 1, "out_channels": 1, "model_channels": 32, "num_res_blocks": 1,
+                                               "data_shape": [16, 16, 16], "attention_resolutions": [4, 8], "use_scale_shift_norm": True,
+                                               "num_heads": 4, "num_classes": 12, "activation": "SiLU", "use_new_attention_order": False,
+                                               "cond_fn": "MultiEmbeddings"}},
+        "dataset": {"name": "SphericalHarmonicDataset", "kwargs": {"max_l": 3, "grid_el": 16, "length": 8}},
+        "optimizer": {"name": "AdamW", "kwargs": {"lr": 0.0001}},
+        "lr_scheduler": {"name": "CosineAnnealingLR", "kwargs": {"T_max": 10, "eta_min": 0.00001}},
+        "noise_schedule": {"name": "LinearSchedule", "kwargs": {"num_steps": 20, "beta_1": 0.001, "beta_T": 0.02}},
+        "training": {"device": "cuda", "np": 1, "loss_fn": "MSELoss", "batch_size": 2, "seed": 777, "benchmark_mode": True},
+        "inference": {"device": "cuda", "checkpoint": "model.pth", "parameter_space": space, "seed": 777},
+    }
+    monkeypatch.chdir(tmp_path)
+    with open("config.json", "w") as f:
+        json.dump(cfg, f)
+    config = ExperimentConfig.from_json("config.json")
+    assert config.model.kwargs["use_new_attention_order"] is False and config.model.kwargs["model_channels"] == 32
+    assert not hasattr(config.training, "benchmark_mode") and config.training.sample_every_n_epochs == 5
+    torch.manual_seed(config.training.seed)
+
+    # ---- training.py
+    schedule = registry.get("schedules", config.noise_schedule.name)(**config.noise_schedule.kwargs)
+    dset = registry.get("datasets", config.dataset.name)(**config.dataset.kwargs)
+    ddpm = diffusion.DDPM(backbone=config.model.name, backbone_kwargs=config.model.kwargs, schedule=schedule,
+                          loss_func=config.training.loss_fn, timesteps=config.noise_schedule.kwargs["num_steps"],
+                          cond_fn=config.model.kwargs["cond_fn"], cond_fn_kwargs={"parameter_space": space, "embedding_dim": 128},
+                          optimizer=config.optimizer.name, opt_kwargs=config.optimizer.kwargs,
+                          sample_every_n_epochs=config.training.sample_every_n_epochs, sampling_batch_size=2,
+                          sample_parameter_space=config.inference.parameter_space).to(config.training.device)
+    assert not ddpm.backbone.input_blocks[-1][1].use_new_attention_order         # JSON false stayed falsy (SURVEY 5.6)
+    trainer = DPTrainer(ddpm)
+    losses = []
+    for _ in range(2):
+        data, _emb = dset.batch(config.training.batch_size)
+        labels = sample_from_discrete_parameter_space(space, config.training.batch_size, random=True, device=data.device)
+        losses.append(float(trainer.step([data, labels])))
+    assert all(math.isfinite(v) for v in losses)
+    ddpm.eval()
+    ddpm.save_model_weights()
+    assert os.path.exists("model.pth")
+    keys = list(torch.load("model.pth", map_location="cpu").keys())
+    assert "cond_fn.embedding_layers.l.weight" in keys and "input_blocks.0.0.weight" in keys
+
+    # ---- inference.py
+    schedule = registry.get("schedules", config.noise_schedule.name)(device=config.inference.device, **config.noise_schedule.kwargs)
+    model = diffusion.GaussianDiffusionPipeline(backbone=config.model.name, backbone_kwargs=config.model.kwargs, schedule=schedule,
+                                                loss_func=config.training.loss_fn, timesteps=config.noise_schedule.kwargs["num_steps"],
+                                                cond_fn=config.model.kwargs["cond_fn"],
+                                                cond_fn_kwargs={"parameter_space": space, "embedding_dim": 128},
+                                                optimizer=config.optimizer.name, opt_kwargs=config.optimizer.kwargs,
+                                                sample_every_n_epochs=config.training.sample_every_n_epochs, sampling_batch_size=3,
+                                                sample_parameter_space=config.inference.parameter_space)
+    model.backbone.load_state_dict(torch.load(config.inference.checkpoint))
+    model.eval()
+    model.to(config.inference.device)
+    pred_images = model.generate(parameter_space=config.inference.parameter_space, random=False)
+    arr = pred_images.cpu().numpy()                                       # inference.py:168-169 writes this to HDF5
+    assert arr.shape == (3, 1, 16, 16, 16) and np.isfinite(arr).all()
+    # the same checkpoint through DDPM.reverse_process gives the trained backbone's samples, not an untrained one's
+    fresh = diffusion.DDPM(backbone=config.model.name, backbone_kwargs=config.model.kwargs, schedule=schedule, loss_func="MSELoss",
+                           timesteps=20, cond_fn="MultiEmbeddings", cond_fn_kwargs={"parameter_space": space, "embedding_dim": 128})
+    fresh.backbone.load_state_dict(torch.load("model.pth"))
+    fresh = fresh.to("cuda").eval()
+    y = sample_from_discrete_parameter_space(space, 2, random=False, device="cuda")
+    x = det_normal((2, 1, 16, 16, 16), "ssx").to("cuda")
+    t = torch.tensor([3, 17], device="cuda")
+    with torch.no_grad():
+        assert torch.equal(fresh.backbone(x, t, y), ddpm.backbone(x, t, y))

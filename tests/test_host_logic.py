@@ -133,3 +133,44 @@ def test_ddpm_constructor_and_optimizer_contract():
     assert opt.param_groups[0]["lr"] == pytest.approx(2e-4)          # lr * sqrt(world)  (abstract_diffusion.py:118)
     assert opt.param_groups[0]["weight_decay"] == 1e-2 and opt.param_groups[0]["betas"] == (0.9, 0.999)
     assert ddpm.hparams.opt_kwargs == {"lr": 1e-4}                    # not mutated
+
+
+def test_experiment_config_loader(tmp_path):
+    """config.py: the attribute surface of the reference's ExperimentConfig (config.py:80-110) from plain JSON; booleans stay
+    booleans, numeric strings are cast (utils.py:223-244), unknown training keys are dropped, missing sections fail."""
+    import json
+    from rho_diffusion_amd.config import ExperimentConfig
+    cfg = {"experiment": "x", "model": {"name": "UNetv2", "kwargs": {"dims": "3", "use_new_attention_order": False, "lr": "1e-4",
+                                                                      "data_shape": [8, "16", 16.0], "flag": True, "act": "SiLU"}},
+           "dataset": {"name": "d", "kwargs": {}}, "optimizer": {"name": "AdamW", "kwargs": {"lr": 0.0001}},
+           "lr_scheduler": {"name": "s", "kwargs": {}}, "noise_schedule": {"name": "LinearSchedule", "kwargs": {"num_steps": 1000.0}},
+           "training": {"device": "xpu", "np": 1, "benchmark_mode": True, "batch_size": "16"},
+           "inference": {"device": "xpu", "checkpoint": "model.pth", "parameter_space": {"l": [1, 2]}}}
+    p = tmp_path / "c.json"
+    p.write_text(json.dumps(cfg))
+    c = ExperimentConfig.from_json(str(p))
+    kw = c.model.kwargs
+    assert kw["dims"] == 3 and isinstance(kw["dims"], int) and kw["lr"] == 1e-4 and kw["data_shape"] == [8, 16, 16]
+    assert kw["use_new_attention_order"] is False and kw["flag"] is True and kw["act"] == "SiLU"
+    assert c.noise_schedule.kwargs["num_steps"] == 1000 and isinstance(c.noise_schedule.kwargs["num_steps"], int)
+    assert c.training.batch_size == 16 and c.training.loss_fn == "MSELoss" and not hasattr(c.training, "np")
+    assert c.inference.parameter_space == {"l": [1, 2]} and c.inference.cache_file is None
+    with pytest.raises(FileNotFoundError):
+        ExperimentConfig.from_json(str(tmp_path / "missing.json"))
+    del cfg["noise_schedule"]
+    p.write_text(json.dumps(cfg))
+    with pytest.raises(ValueError):
+        ExperimentConfig.from_json(str(p))
+
+
+def test_alias_makes_reference_imports_resolve_here():
+    import sys
+    RA.install_alias()
+    import rho_diffusion
+    from rho_diffusion.registry import registry as reg2
+    from rho_diffusion.diffusion import DDPM
+    from rho_diffusion.diffusion.diffusers import DiffusersDDPMPipeline
+    assert rho_diffusion is RA and reg2 is registry and DDPM is RA.diffusion.DDPM and DiffusersDDPMPipeline is RA.diffusion.DiffusersDDPMPipeline
+    assert registry.get("datasets", "SphericalHarmonicDataset") is RA.data.SphericalHarmonicDataset
+    for k in [k for k in sys.modules if k == "rho_diffusion" or k.startswith("rho_diffusion.")]:
+        del sys.modules[k]
