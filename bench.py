@@ -46,7 +46,40 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--dump-ops", default=None, help="write the per-launch profile (kind, shape, ms, TFLOP/s) to this file")
-    return ap.parse_args()
+    ap.add_argument("--labels", action="store_true",
+                    help="class-conditional backbone: num_classes=25, MultiEmbeddings(embedding_dim=4*mc) over the DeepGalaxy "
+                         "parameter space, y [B, 4] (BASELINE configs[4]; needs --mc 32 for the reference's embedding_dim=128)")
+    ap.add_argument("--config", choices=sorted(PRESETS), default=None,
+                    help="BASELINE.json configuration preset (sets --dims/--grid/--mc/--batch/--dtype/--labels); default = c3")
+    args = ap.parse_args()
+    if args.config:
+        for k, v in PRESETS[args.config].items():
+            setattr(args, k, v)
+    return args
+
+
+# BASELINE.json configs (c1 .. c5; c4 = c3 on 8 GPUs, i.e. `--gpus 8` with the c3 preset)
+PRESETS = {
+    "c1": dict(dims=2, grid=64, mc=64, batch=16, dtype="fp32", labels=False),
+    "c2": dict(dims=2, grid=128, mc=64, batch=64, dtype="fp32", labels=False),
+    "c3": dict(dims=3, grid=64, mc=64, batch=32, dtype="bf16", labels=False),
+    "c5": dict(dims=3, grid=128, mc=32, batch=2, dtype="bf16", labels=True),
+}
+DEEP_GALAXY_SPACE = {"s": [0.25, 0.5, 0.75, 1, 1.25, 1.5], "m": [0.25, 0.5, 0.75, 1, 1.25, 1.5],
+                     "t": list(range(300, 655, 5)), "c": list(range(14))}          # rho_diffusion/data/deep_galaxy.py:41-47
+
+
+def workload_name(args, world):
+    """Derived from the arguments; names the BASELINE config only when the arguments ARE that config."""
+    which = None
+    for name, pz in PRESETS.items():
+        if all(getattr(args, k) == v for k, v in pz.items()):
+            which = {"c1": "configs[0]", "c2": "configs[1]", "c3": "configs[2]" if world == 1 else f"configs[3] on {world} GPUs",
+                     "c5": "configs[4] geometry (batch 2/GPU)"}[name]
+    tag = f"BASELINE {which}" if which else "custom configuration, not a BASELINE config"
+    cond = ", class-conditional (MultiEmbeddings y[B,4])" if args.labels else ""
+    return (f"DDPM reverse step, UNetv2 {args.dims}D {args.grid}^{args.dims} mc={args.mc}{cond} ({tag}), batch {args.batch}/GPU, "
+            f"{args.dtype}, LinearSchedule(1000,1e-3,0.02)")
 
 
 def build_model(args, device):
@@ -59,7 +92,11 @@ def build_model(args, device):
     kw = dict(data_shape=[args.grid] * args.dims, in_channels=1, out_channels=1, model_channels=args.mc,
               num_res_blocks=2, channel_mult=(1, 2, 4, 8), attention_resolutions=[16, 8], num_heads=4,
               use_scale_shift_norm=True, dims=args.dims, activation="SiLU", compute_dtype=args.dtype)
-    ddpm = DDPM(UNet, kw, LinearSchedule(1000, 1e-3, 0.02), nn.MSELoss, timesteps=1000)
+    extra = {}
+    if args.labels:
+        kw["num_classes"] = 25
+        extra = dict(cond_fn="MultiEmbeddings", cond_fn_kwargs={"parameter_space": DEEP_GALAXY_SPACE, "embedding_dim": 4 * args.mc})
+    ddpm = DDPM(UNet, kw, LinearSchedule(1000, 1e-3, 0.02), nn.MSELoss, timesteps=1000, **extra)
     with torch.no_grad():
         for p in ddpm.backbone.parameters():
             if float(p.abs().max()) == 0.0:
@@ -72,6 +109,12 @@ def hip_ws_bytes(batch):
     return int(hip.lib().rho_abs_quantile_workspace_bytes(batch))
 
 
+def labels_for(batch, device):
+    keys = list(DEEP_GALAXY_SPACE)
+    rows = [[float(DEEP_GALAXY_SPACE[k][(3 * i + 5 * j + 1) % len(DEEP_GALAXY_SPACE[k])]) for j, k in enumerate(keys)] for i in range(batch)]
+    return torch.tensor(rows, dtype=torch.float32, device=device)
+
+
 def cpu_baseline(kw, ddpm, args):
     """The CPU oracle (fp32, stock PyTorch CPU ops == what the reference executes) timed on this
     host's cores for a bounded sample: B=1 denoising steps, scaled linearly to the bench batch."""
@@ -80,7 +123,7 @@ def cpu_baseline(kw, ddpm, args):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    n_threads = max(1, min(avail, 32))      # a GPU box's CPU share; more threads oversubscribe the ATen pool
+    n_threads = max(1, avail)               # every core this process may run on; os.cpu_count() is reported beside it
     torch.set_num_threads(n_threads)
     sd = {k: v.detach().float().cpu() for k, v in ddpm.backbone.state_dict().items()}
     cfg = {k: v for k, v in kw.items() if k != "compute_dtype"}
@@ -93,11 +136,13 @@ def cpu_baseline(kw, ddpm, args):
         for i in range(args.cpu_steps + 1):
             t0 = time.perf_counter()
             t = 999 - i
-            pred = R.unet_forward(sd, cfg, x, torch.full((1,), t, dtype=torch.long))
+            yb = labels_for(1, "cpu") if args.labels else None
+            pred = R.unet_forward(sd, cfg, x, torch.full((1,), t, dtype=torch.long), yb, DEEP_GALAXY_SPACE if args.labels else None)
             x = R.p_sample_step(x, pred, t, sched, z)
             times.append(time.perf_counter() - t0)
     per_b1 = sum(times[1:]) / max(1, len(times) - 1)
-    return {"value": 1.0 / (per_b1 * args.batch), "unit": "denoising_steps/s", "cores": n_threads, "kind": "port",
+    return {"value": 1.0 / (per_b1 * args.batch), "unit": "denoising_steps/s", "cores": n_threads, "host_cpu_count": os.cpu_count(),
+            "kind": "port",
             "sample": f"B=1 of {args.batch}, {args.cpu_steps} timed steps after 1 warm-up ({per_b1:.2f} s per B=1 step), "
                       f"scaled x{args.batch} in time; fp32 oracle (oracle/ref_torch.py)"}
 
@@ -131,18 +176,33 @@ def roofline_of(plan, args):
         dump_ops(args.dump_ops, prof)
     peak = MFMA_PEAK_TFLOPS[args.dtype]
     achieved = fl / (ms * 1e-3) / 1e12
-    # HBM traffic of the same launches from PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
-    # --pmc passes; collected offline with rocprofv3 on this command, see profiles/): bench.py cannot run the profiler
-    traffic = traffic_note = None
-    tpath = os.path.join(ROOT, "profiles", "r01h_pmc_traffic_conv3.json")
-    if os.path.exists(tpath) and args.dtype == "bf16" and args.batch == 32 and args.grid == 64 and args.dims == 3 and args.mc == 64:
+    # HBM traffic + MFMA utilisation of the same launches from PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+    # SQ_INSTS_MFMA: separate --pmc passes collected with rocprofv3 on this command, tests/gpu_pmc.sh -> tools/pmc_summary.py).
+    # bench.py cannot run the profiler itself, so the summary is only used when it was measured on THIS binary (build id of
+    # rho_build_info()) and this workload; otherwise traffic is null and the reason is stated.
+    from rho_diffusion_amd import hip
+    build = hip.lib().rho_build_info().decode().rsplit("build ", 1)[-1]
+    traffic = mfma_util = None
+    traffic_note = "no PMC summary under profiles/ for this binary"
+    import glob
+    for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_conv3.json")), reverse=True):
         with open(tpath) as f:
             tj = json.load(f)
-        traffic, traffic_note = tj["hbm_bytes_per_launch"], "profiles/r01h_pmc_traffic_conv3.json (PMC FETCH_SIZE x2 + WRITE_SIZE, average per launch of the same conv3 launches)"
+        if tj.get("build_id") != build:
+            traffic_note = (f"{os.path.relpath(tpath, ROOT)} was measured on build {tj.get('build_id', '(unrecorded)')}, this is {build}: "
+                            "not reported (re-run tests/gpu_pmc.sh)")
+            continue
+        if tj.get("workload") != dict(dims=args.dims, grid=args.grid, mc=args.mc, batch=args.batch, dtype=args.dtype, labels=args.labels):
+            traffic_note = f"{os.path.relpath(tpath, ROOT)} covers another workload"
+            continue
+        traffic, mfma_util = tj["hbm_bytes_per_launch"], tj.get("mfma_util")
+        traffic_note = f"{os.path.relpath(tpath, ROOT)} (build {build}; PMC FETCH_SIZE x2 + WRITE_SIZE, average per launch of the same conv3 launches)"
+        break
     alg_bytes = sum(p["bytes"] for p in conv3)
     return {
         "bound": "mfma", "kernel": "k_conv (3x3x3 implicit GEMM, LDS halo tile)", "achieved": achieved, "peak": peak,
-        "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_note,
+        "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_note, "mfma_util": mfma_util,
+        "build_id": build,
         "algorithmic_bytes_per_launch": alg_bytes / max(1, len(conv3)), "algorithmic_flops_per_launch": fl / max(1, len(conv3)),
         "launches_per_step": len(conv3), "avg_launch_ms": ms / max(1, len(conv3)),
         "algorithmic_bytes_per_step": alg_bytes, "algorithmic_flops_per_step": fl, "kernel_ms_per_step": ms,
@@ -189,19 +249,26 @@ def main():
         dist.all_reduce(w)
 
     def timed(step_fn, steps, warmup):
+        """(wall seconds for `steps` steps, max over ranks; per-step HIP-event durations in ms on this rank).  The events sit on
+        the stream the step is launched on; recording them costs nothing measurable against a >= 1 ms step."""
         for _ in range(warmup):
             step_fn()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        evs[0].record()
+        for i in range(steps):
             step_fn()
+            evs[i + 1].record()
         barrier()
         dt = time.perf_counter() - t0
+        per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
         if world > 1:
             tt = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        return dt
+        med = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
+        return dt, med
 
     if args.mode in ("sample", "both"):
         x_t = ddpm.noise(torch.empty(shape, device=device))
@@ -209,10 +276,12 @@ def main():
         t_dev = torch.full((1,), 999, dtype=torch.int32, device=device)
         off_dev = torch.full((1,), 1 << 32, dtype=torch.int64, device=device)
         n_elem = x_t.numel()
+        # labels are embedded once per chain (DDPM.reverse_process does the same through _preembed_conditions): the step gets [B, 4 mc]
+        cc = ddpm._preembed_conditions(labels_for(B, device)) if args.labels else None
 
         def sample_step():
             ops.philox_normal(z, ddpm.noise_seed, 0, offset_dev=off_dev)
-            pred = engine.forward(x_t, None, None, t_scalar_dev=t_dev)
+            pred = engine.forward(x_t, None, cc, t_scalar_dev=t_dev)
             ops.p_sample_step(x_t, pred, z, tables["coef"], t_dev)
             ops.step_advance(t_dev, off_dev, (n_elem + 3) // 4)
 
@@ -229,9 +298,9 @@ def main():
             except Exception as exc:  # noqa: BLE001
                 torch.cuda.synchronize()
                 print(f"[bench] HIP graph capture failed ({type(exc).__name__}: {exc}); eager launches", file=sys.stderr)
-        dt = timed(step_fn, args.steps, args.warmup)
+        dt, med = timed(step_fn, args.steps, args.warmup)
         assert torch.isfinite(x_t).all(), "non-finite state after the timed steps"
-        results["sample"] = dict(dt=dt, steps=args.steps, graphed=graphed)
+        results["sample"] = dict(dt=dt, steps=args.steps, graphed=graphed, median_ms=med)
         if rank == 0 and not args.no_roofline:
             roofline = roofline_of(next(iter(engine._plans.values())), args)
 
@@ -246,20 +315,22 @@ def main():
         qws = torch.empty((hip_ws_bytes(B) + 3) // 4, dtype=torch.int32, device=device)
         state = {"t": 999}
 
+        ccd = ddpm._preembed_conditions(labels_for(B, device)) if args.labels else None
+
         def ddim_step():
-            x0_hat = engine.forward(xd, None, None, t_scalar_dev=td)
+            x0_hat = engine.forward(xd, None, ccd, t_scalar_dev=td)
             c = ddim_coefficients(gtab, state["t"], 0.0)
             ops.abs_quantile(x0_hat, 0.9, out=quant, workspace=qws)
             ops.ddim_step(xd, x0_hat, quant, None, xd, None, *c)
             ops.step_advance(td, None, 0)
             state["t"] = max(state["t"] - 1, 1)
 
-        dt = timed(ddim_step, args.steps, args.warmup)
+        dt, med = timed(ddim_step, args.steps, args.warmup)
         assert torch.isfinite(xd).all(), "non-finite DDIM state after the timed steps"
-        results["ddim"] = dict(dt=dt, steps=args.steps)
+        results["ddim"] = dict(dt=dt, steps=args.steps, median_ms=med)
         if rank == 0 and not args.no_roofline:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-            x0_hat = engine.forward(xd, None, None, t_scalar_dev=td)
+            x0_hat = engine.forward(xd, None, ccd, t_scalar_dev=td)
             torch.cuda.synchronize()
             ev[0].record()
             ops.abs_quantile(x0_hat, 0.9, out=quant, workspace=qws)
@@ -271,20 +342,22 @@ def main():
             results["ddim"]["update_ms"] = ev[1].elapsed_time(ev[2])
 
     if args.mode in ("train", "both"):
-        # synthetic spherical-harmonics density fields (rho_diffusion/data/synthetic.py:45-124), pool generated once
-        from rho_diffusion_amd.data import SphericalHarmonicPool   # host generator (scipy), built once, not timed
-        data = SphericalHarmonicPool(args.grid, args.dims, size=8, seed=777 + rank).batch(B, device)
+        # synthetic spherical-harmonics density fields (rho_diffusion/data/synthetic.py:45-124) generated ON THE DEVICE
+        # (rho_sph_harm_fields), a pool of 8 built once before the timed region
+        from rho_diffusion_amd.data import SphericalHarmonicPool
+        data = SphericalHarmonicPool(args.grid, args.dims, size=8, seed=777 + rank, device=device).batch(B)
+        batch = [data, labels_for(B, device)] if args.labels else data
         from rho_diffusion_amd.trainer import DPTrainer
         trainer = DPTrainer(ddpm, lr=1e-4)
         last = {}
 
         def train_step():
-            last["loss"] = trainer.step(data)
+            last["loss"] = trainer.step(batch)
 
         tsteps = args.train_steps or args.steps
-        dt = timed(train_step, tsteps, max(1, args.warmup))
+        dt, med = timed(train_step, tsteps, max(1, args.warmup))
         assert torch.isfinite(last["loss"]).all(), "non-finite training loss"
-        results["train"] = dict(dt=dt, steps=tsteps, loss=float(last["loss"].detach()),
+        results["train"] = dict(dt=dt, steps=tsteps, loss=float(last["loss"].detach()), median_ms=med,
                                 peak_mem_gb=round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1))
         if rank == 0 and not args.no_roofline:
             tp = engine._last_train_plan
@@ -292,6 +365,21 @@ def main():
             fk, bk = by_kind(tp.profile(repeats=1)), by_kind(bprof)
             if args.dump_ops:
                 dump_ops(args.dump_ops + ".bwd", bprof)
+            # training roofline (SURVEY 8d "per training sample": fwd + dgrad + wgrad + the attention recompute): algorithmic
+            # FLOPs of the MFMA kernels of one step against the bf16 / fp32 matrix peak, whole step and per kind
+            peak = MFMA_PEAK_TFLOPS[args.dtype]
+            mf = {("fwd", k): v for k, v in fk.items() if v["flops"] > 0 and k in ("conv3", "conv1", "attention")}
+            mf.update({("bwd", k): v for k, v in bk.items() if v["flops"] > 0 and k in ("wgrad", "dgrad", "attention_bwd")})
+            tot_fl = sum(v["flops"] for v in mf.values())
+            step_ms = 1e3 * dt / tsteps
+            results["train"]["roofline"] = {
+                "bound": "mfma", "peak": peak, "unit": "TFLOP/s", "algorithmic_flops_per_step": tot_fl,
+                "algorithmic_flops_per_sample": tot_fl / B, "ideal_ms_per_step": tot_fl / (peak * 1e12) * 1e3,
+                "achieved": tot_fl / (step_ms * 1e-3) / 1e12, "frac": tot_fl / (step_ms * 1e-3) / 1e12 / peak,
+                "per_kind": {f"{d}.{k}": {"ms": round(v["ms"], 2), "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
+                                          "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak, 3)} for (d, k), v in mf.items()},
+                "non_mfma_ms": round(sum(v["ms"] for k, v in fk.items() if ("fwd", k) not in mf)
+                                     + sum(v["ms"] for k, v in bk.items() if ("bwd", k) not in mf), 2)}
             results["train"]["breakdown"] = {"fwd": {k: round(v["ms"], 2) for k, v in fk.items()},
                                              "bwd": {k: round(v["ms"], 2) for k, v in bk.items()},
                                              "bwd_TFLOPs": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in bk.items()
@@ -310,19 +398,18 @@ def main():
         "metric": metric, "value": value, "unit": unit, "n_gpus": world,
         "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"DDPM reverse step, UNetv2 {args.dims}D {args.grid}^{args.dims} mc={args.mc} "
-                               f"(BASELINE configs[2]), batch {B}/GPU, LinearSchedule(1000,1e-3,0.02)",
-                   "global_batch": B * world,
+        "config": {"workload": workload_name(args, world), "global_batch": B * world,
                    "parallelism": f"independent samples x{world} (sampling: no data-path collective; training: DP gradient "
                                   f"all-reduce over RCCL, overlapped with backward)"},
     }
     if "sample" in results:
         out["config"]["hip_graph"] = bool(results["sample"].get("graphed"))
+        out["ms_per_step_hipevent_median"] = results["sample"]["median_ms"]
         out["config"]["sample_steps_per_sec"] = world * B * results["sample"]["steps"] / results["sample"]["dt"]
     if "ddim" in results:
         r = results["ddim"]
         out["ddim_sampling"] = {"metric": "denoising_steps_per_sec", "value": world * r["steps"] / r["dt"], "unit": "steps/s",
-                                "ms_per_step": 1e3 * r["dt"] / r["steps"],
+                                "ms_per_step": 1e3 * r["dt"] / r["steps"], "ms_per_step_hipevent_median": r["median_ms"],
                                 "step": "UNetv2 x0-prediction + exact per-sample 0.9-quantile of |x0| (radix select) + fused DDIM "
                                         "update (GaussianDiffusionPipeline.reverse_process, eta = 0, cosine betas)"}
         for k_ in ("quantile_ms", "update_ms"):
@@ -331,7 +418,8 @@ def main():
     if "train" in results:
         r = results["train"]
         out["training"] = {"metric": "training_samples_per_sec", "value": world * B * r["steps"] / r["dt"], "unit": "samples/s",
-                           "steps": r["steps"], "ms_per_step": 1e3 * r["dt"] / r["steps"], "loss": r["loss"],
+                           "steps": r["steps"], "ms_per_step": 1e3 * r["dt"] / r["steps"], "ms_per_step_hipevent_median": r["median_ms"],
+                           "loss": r["loss"],
                            "peak_mem_gb": r.get("peak_mem_gb"),
                            "step": "q_sample + UNetv2 fwd + MSE + bwd + " + ("RCCL grad all-reduce + " if world > 1 else "") + "fused AdamW"}
 
@@ -339,6 +427,7 @@ def main():
         out["roofline"] = roofline
     if "train" in results and results["train"].get("breakdown"):
         out["training"]["by_kind_ms"] = results["train"]["breakdown"]
+        out["training"]["roofline"] = results["train"]["roofline"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(kw, ddpm, args)
     if rank == 0:

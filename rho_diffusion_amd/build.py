@@ -28,18 +28,35 @@ def _newer(src_paths, target) -> bool:
     return any(os.path.getmtime(s) > t for s in src_paths)
 
 
+def source_id() -> str:
+    """sha256 (12 hex digits) over every source and header of the library: reported by rho_build_info(), stored next to
+    profiler summaries, so a measurement can be matched to the binary it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + [os.path.join(INCLUDE, "rho_hip.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
 def build(verbose: bool = True, force: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(INCLUDE, "rho_hip.h")]
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    sid = source_id()
+    idfile = os.path.join(CSRC, ".build_id")
+    old = open(idfile).read().strip() if os.path.exists(idfile) else ""
     objs = []
     jobs = []
     for s in srcs:
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _newer([src] + headers, obj):
-            jobs.append([hipcc, *FLAGS, "-c", src, "-o", obj])
+        stamp = s == "elementwise.hip" and old != sid          # rho_build_info() lives there and carries the id
+        if force or stamp or _newer([src] + headers, obj):
+            jobs.append([hipcc, *FLAGS, f'-DRHO_BUILD_ID="{sid}"', "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -54,6 +71,8 @@ def build(verbose: bool = True, force: bool = False) -> str:
         list(ex.map(run, jobs))
     if force or jobs or _newer(objs, LIB):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    with open(idfile, "w") as f:
+        f.write(sid)
     return LIB
 
 

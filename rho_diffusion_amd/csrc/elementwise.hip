@@ -11,7 +11,12 @@ static inline int grid_for(int64_t work_items, int block) {
 }
 
 extern "C" int rho_abi_version(void) { return 1; }
-extern "C" const char* rho_build_info(void) { return "librho_hip gfx950 (CDNA4) hipcc -O3; MFMA 16x16x32 + 32x32x16 bf16 / 32x32x2 f32"; }
+#ifndef RHO_BUILD_ID
+#define RHO_BUILD_ID "unstamped"
+#endif
+extern "C" const char* rho_build_info(void) {
+    return "librho_hip gfx950 (CDNA4) hipcc -O3; MFMA 16x16x32 + 32x32x16 bf16 / 32x32x2 f32; build " RHO_BUILD_ID;
+}
 
 // ----------------------------------------------------------------------------- q_sample
 // ddpm.py:122-129: x_t = sqrt(abar_t)*x0 + sqrt(1-abar_t)*eps, abar gathered per batch element.

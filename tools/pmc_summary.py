@@ -25,6 +25,22 @@ def collect(sub):
     return agg, calls
 
 
+meta = {}
+mpath = os.path.join(ROOT, "gpurun_out", PMC_DIR, "meta.json")
+if os.path.exists(mpath):
+    meta = json.load(open(mpath))
+
+
+def durations():
+    """kernel name -> summed duration in seconds over the un-instrumented trace pass (tests/gpu_pmc.sh `trace`)."""
+    dur = collections.defaultdict(float)
+    files = glob.glob(os.path.join(ROOT, "gpurun_out", PMC_DIR, "trace", "**/*kernel_trace.csv"), recursive=True)
+    for f in sorted(files, key=os.path.getmtime)[-1:]:
+        for r in csv.DictReader(open(f)):
+            dur[r["Kernel_Name"]] += (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-9
+    return dur
+
+
 sq = collections.defaultdict(dict)
 for sub in ("sq1", "sq2", "fetch", "write"):
     agg, calls = collect(sub)
@@ -40,7 +56,17 @@ for k, v in sq.items():
     if v.get("SQ_WAVE_CYCLES"):
         v["WAIT_INST_ANY_frac"] = v.get("SQ_WAIT_INST_ANY", 0) / v["SQ_WAVE_CYCLES"]
         v["WAIT_ANY_frac"] = v.get("SQ_WAIT_ANY", 0) / v["SQ_WAVE_CYCLES"]
-    out[k[:70]] = v
+    out[k[:110]] = v
+# MFMA utilisation against the gfx950 peak issue rate: wave-level MFMA instructions x SIMD cycles each (32 for 32x32x16 bf16,
+# 16 for 16x16x32 bf16, 64 for 32x32x2 f32: MI355X_MICROARCH.md cycle constants) / (1024 SIMDs x kernel time x 2.4 GHz)
+DUR = durations()
+for k, v in sq.items():
+    if v.get("SQ_INSTS_MFMA") and DUR.get(k):
+        is_m16 = k.rstrip(")").rstrip().endswith("true>(ConvK") or ", true>" in k
+        cyc = 64.0 if "<float" in k else (16.0 if (is_m16 and "k_conv" in k) else 32.0)
+        v["duration_s_trace_pass"] = DUR[k]
+        v["mfma_cycles_per_inst_assumed"] = cyc
+        v["mfma_util"] = v["SQ_INSTS_MFMA"] * cyc / (1024.0 * DUR[k] * 2.4e9)
 suffix = "" if PMC_DIR == "pmc" else "_train"
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc{suffix}_sq_counters_summary.json"), "w"), indent=1)
 if PMC_DIR != "pmc":
@@ -50,7 +76,12 @@ conv3 = [k for k in sq if "k_conv<" in k and "3, 3, 3" in k]
 fetch = sum(sq[k].get("FETCH_SIZE", 0.0) for k in conv3) * 1024.0 * 2.0
 write = sum(sq[k].get("WRITE_SIZE", 0.0) for k in conv3) * 1024.0
 launches = sum(sq[k].get("_calls_fetch", 0) for k in conv3)
-tj = {"kernel": "k_conv<bf16,3,3,3,*> (all variants)",
+mf = sum(sq[k].get("SQ_INSTS_MFMA", 0.0) * sq[k].get("mfma_cycles_per_inst_assumed", 32.0) for k in conv3)
+dsum = sum(DUR.get(k, 0.0) for k in conv3)
+tj = {"kernel": "k_conv<bf16,3,3,3,*> (all variants)", "build_id": meta.get("build_id"), "workload": meta.get("workload"),
+      "mfma_util": (mf / (1024.0 * dsum * 2.4e9)) if dsum > 0 else None,
+      "mfma_util_note": "sum over the conv3 variants of SQ_INSTS_MFMA x SIMD cycles per instruction / (1024 SIMDs x summed kernel time "
+                        "of the un-instrumented trace pass x 2.4 GHz)",
       "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --mode sample --steps 2 "
                  f"--warmup 1 ({steps:g} executions of the step profiled; tests/gpu_pmc.sh, tools/pmc_summary.py)",
       "launches_profiled": launches, "launches_per_step": launches / steps,
