@@ -123,7 +123,9 @@ def cpu_baseline(kw, ddpm, args):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    n_threads = max(1, avail)               # every core this process may run on; os.cpu_count() is reported beside it
+    # the GPU box hands a one-GPU job a share of its cores while sched_getaffinity / os.cpu_count() still report all 256: with 256
+    # ATen threads a B=1 step took 70 s instead of 4 s (measured, r02).  32 threads = the r01 setting; both counts are reported.
+    n_threads = max(1, min(avail, 32))
     torch.set_num_threads(n_threads)
     sd = {k: v.detach().float().cpu() for k, v in ddpm.backbone.state_dict().items()}
     cfg = {k: v for k, v in kw.items() if k != "compute_dtype"}
