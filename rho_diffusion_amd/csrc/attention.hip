@@ -65,51 +65,62 @@ __global__ __launch_bounds__(256, CH <= 128 ? 2 : 1) void k_attn_bf16(const bf16
     // m_run is kept in the scaled base-2 domain; the logits stay raw and are scaled inside the exponent's FMA
     const float sc = scale_log2e;
 
-    for (int kt0 = 0; kt0 < T; kt0 += KT) {
-        __syncthreads();  // previous tile fully consumed
-        // ---- stage K tile [KT keys][CH] and V^T tile [CH][KT keys]
-        {
-            uint4 kv[KIT];
+    // K / V^T tiles: issue-early / write-late (cdna_hip_programming.md T14).  The global loads of tile t+1 are issued into
+    // registers BEFORE the MFMA / softmax work of tile t and written to LDS after it, so their latency (HBM or L2) runs under
+    // ~2 us of compute instead of in front of it; r01 loaded, waited and wrote each tile between two barriers with only the
+    // other workgroup of the CU to cover the wait.
+    uint4 kv[KIT], vv[VIT];
+    auto load_tile = [&](int kt0) {                  // branch-free (clamped addresses, zeroed at write time): counted vmcnt
 #pragma unroll
-            for (int i = 0; i < KIT; ++i) {
+        for (int i = 0; i < KIT; ++i) {
+            const int pc = tid + 256 * i;
+            const int key = pc / KPC, piece = pc % KPC;
+            const int kc = min(kt0 + (KEXACT ? key : min(key, KT - 1)), T - 1);
+            kv[i] = *reinterpret_cast<const uint4*>(kbase + (size_t)kc * row2c + piece * 8);
+        }
+        if (vec_v) {
+#pragma unroll
+            for (int i = 0; i < VIT; ++i) {
                 const int pc = tid + 256 * i;
-                const int key = pc / KPC, piece = pc % KPC;
-                const int kc = min(kt0 + (KEXACT ? key : min(key, KT - 1)), T - 1);   // clamped, zeroed below: branch-free loads
-                kv[i] = *reinterpret_cast<const uint4*>(kbase + (size_t)kc * row2c + piece * 8);
-            }
-            if (vec_v) {
-                uint4 vv[VIT];
-#pragma unroll
-                for (int i = 0; i < VIT; ++i) {
-                    const int pc = tid + 256 * i;
-                    const int c = pc / VPC, piece = pc % VPC;
-                    const bool ok = (VIT * 256 == NCT * 32 * VPC || pc < NCT * 32 * VPC) && c < CH && kt0 + piece * 8 < T;
-                    vv[i] = *reinterpret_cast<const uint4*>(vbase + (size_t)(ok ? c : 0) * T + (ok ? kt0 + piece * 8 : 0));
-                    if (!ok) vv[i] = make_uint4(0u, 0u, 0u, 0u);
-                }
-#pragma unroll
-                for (int i = 0; i < VIT; ++i) {
-                    const int pc = tid + 256 * i;
-                    const int c = pc / VPC, piece = pc % VPC;
-                    if (VIT * 256 == NCT * 32 * VPC || pc < NCT * 32 * VPC) *reinterpret_cast<uint4*>(v_lds + c * VP + piece * 16) = vv[i];
-                }
-            } else {
-                for (int e = tid; e < NCT * 32 * KT; e += 256) {
-                    const int c = e / KT, key = e % KT;
-                    bf16_raw v = 0;
-                    if (c < CH && kt0 + key < T) v = vbase[(size_t)c * T + kt0 + key];
-                    *reinterpret_cast<bf16_raw*>(v_lds + c * VP + key * 2) = v;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < KIT; ++i) {
-                const int pc = tid + 256 * i;
-                const int key = pc / KPC, piece = pc % KPC;
-                if (KEXACT || pc < KT * KPC)
-                    *reinterpret_cast<uint4*>(k_lds + key * KP + piece * 16) = (kt0 + key < T) ? kv[i] : make_uint4(0u, 0u, 0u, 0u);
+                const int c = pc / VPC, piece = pc % VPC;
+                const bool ok = (VIT * 256 == NCT * 32 * VPC || pc < NCT * 32 * VPC) && c < CH && kt0 + piece * 8 < T;
+                vv[i] = *reinterpret_cast<const uint4*>(vbase + (size_t)(ok ? c : 0) * T + (ok ? kt0 + piece * 8 : 0));
             }
         }
-        __syncthreads();
+    };
+    auto store_tile = [&](int kt0) {
+        if (vec_v) {
+#pragma unroll
+            for (int i = 0; i < VIT; ++i) {
+                const int pc = tid + 256 * i;
+                const int c = pc / VPC, piece = pc % VPC;
+                const bool ok = (VIT * 256 == NCT * 32 * VPC || pc < NCT * 32 * VPC) && c < CH && kt0 + piece * 8 < T;
+                if (VIT * 256 == NCT * 32 * VPC || pc < NCT * 32 * VPC)
+                    *reinterpret_cast<uint4*>(v_lds + c * VP + piece * 16) = ok ? vv[i] : make_uint4(0u, 0u, 0u, 0u);
+            }
+        } else {                                     // T not a multiple of 8 (tiny test shapes): element-wise fill
+            for (int e = tid; e < NCT * 32 * KT; e += 256) {
+                const int c = e / KT, key = e % KT;
+                bf16_raw v = 0;
+                if (c < CH && kt0 + key < T) v = vbase[(size_t)c * T + kt0 + key];
+                *reinterpret_cast<bf16_raw*>(v_lds + c * VP + key * 2) = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < KIT; ++i) {
+            const int pc = tid + 256 * i;
+            const int key = pc / KPC, piece = pc % KPC;
+            if (KEXACT || pc < KT * KPC)
+                *reinterpret_cast<uint4*>(k_lds + key * KP + piece * 16) = (kt0 + key < T) ? kv[i] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt0 = 0; kt0 < T; kt0 += KT) {
+        const bool more = kt0 + KT < T;
+        if (more) load_tile(kt0 + KT);               // in flight under this tile's MFMAs
 
         // ---- S^T for the 32-key sub-tiles
         f32x16_t s[NU];
@@ -190,6 +201,11 @@ __global__ __launch_bounds__(256, CH <= 128 ? 2 : 1) void k_attn_bf16(const bf16
                                                                    o[ct], 0, 0, 0);
                 }
             }
+        if (more) {
+            __syncthreads();                         // this tile's LDS fragments are consumed by every wave
+            store_tile(kt0 + KT);
+            __syncthreads();
+        }
     }
 
     // ---- normalise and store: lane holds channels 32*ct + 8*rg + 4*half + {0..3} of query qi

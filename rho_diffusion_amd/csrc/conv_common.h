@@ -73,7 +73,15 @@ __device__ __forceinline__ void mma_step(const uint4& a, const uint4& b, f32x16_
 
 template <>
 __device__ __forceinline__ void mma_step<bf16_raw>(const uint4& a, const uint4& b, f32x16_t& acc) {
+#ifdef RHO_PROBE_M16   /* TIMING-ONLY probe build (wrong numerics): the same FLOPs as two 16x16x32 MFMAs */
+    f32x4_t v0 = {acc[0], acc[1], acc[2], acc[3]}, v1 = {acc[4], acc[5], acc[6], acc[7]};
+    v0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), v0, 0, 0, 0);
+    v1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), v1, 0, 0, 0);
+    acc[0] = v0[0]; acc[1] = v0[1]; acc[2] = v0[2]; acc[3] = v0[3];
+    acc[4] = v1[0]; acc[5] = v1[1]; acc[6] = v1[2]; acc[7] = v1[3];
+#else
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+#endif
 }
 template <>
 __device__ __forceinline__ void mma_step<float>(const uint4& a, const uint4& b, f32x16_t& acc) {

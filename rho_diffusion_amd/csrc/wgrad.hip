@@ -14,6 +14,7 @@
 // The exact-f32 variant (v_mfma_f32_32x32x2_f32) needs one k per lane, i.e. plain ds_read_b32.
 #include <cstdio>
 #include <type_traits>
+#include <utility>
 
 #include "conv_common.h"
 
@@ -46,6 +47,20 @@ struct WgradK {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}).  Register arrays indexed
+// through a lambda parameter end up in scratch memory unless the index is a constant expression.
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+// source of the LDS-DMA lanes that must deliver zeros (conv padding, rows beyond the tile, channels beyond dy_width)
+__device__ uint4 g_wgrad_zero[4];
+
 // 32(row/col) x 16(k) bf16 MFMA operand out of a row-major [k][channel] LDS tile: lane (col = l&31,
 // half = l>>5) gets k = 8*half + {0..7}.  Per 16-lane group the transposing read takes row addresses
 // from lanes 4q+p (row q, columns 4p..4p+3) and returns column i of the 4 rows to lane i.
@@ -61,7 +76,9 @@ __device__ __forceinline__ uint4 tr_frag(const char* lds, int r0, int r1) {
     return f;
 }
 
-template <typename T, int KD, int KH, int KW, int MAXP>
+// PRE: the folded GroupNorm affine + SiLU is applied while the halo is staged (p.pre_a != NULL); a compile-time switch so that
+// the common training path (input materialised by rho_gn_apply, PRE = false) keeps its staging code free of branches.
+template <typename T, int KD, int KH, int KW, int MAXP, bool PRE>
 __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CK = ET<T>::CK;
@@ -74,9 +91,18 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     constexpr bool IS_BF16 = sizeof(T) == 2;
     constexpr int NKS = TAPSPLIT ? 16 : 4;           // 16-position k-steps of this wave per tile
     constexpr bool KEEP_REL = (MAXP <= 10);          // big-halo (strided) variant recomputes instead of holding registers
+    // PIPE (bf16, regular halo): the LDS tiles are DOUBLE-BUFFERED (2 x (40 KB halo + 32 KB dY) = 144 of the 160 KB) and the staging
+    // of tile t+1 (registers -> LDS) plus the global loads of tile t+2 are dealt one slot per k-step INTO the MFMA phase of tile t,
+    // one barrier per tile.  The single-buffered form ran load-wait / LDS-write / barrier / address set-up as a serial phase per
+    // tile with nothing to overlap it (one wave per SIMD: 224 accumulator registers) - PMC r01h: the matrix pipe busy 57 % of the
+    // wave's cycles, 19 % in staging VALU, 18 % parked in waits.
+    constexpr bool PIPE = IS_BF16 && KEEP_REL;
+    constexpr int XBUF = MAXP * 64 * XP;
+    constexpr int DBUF = 256 * DYP;
+    constexpr int BUF = XBUF + DBUF;
 
     char* const halo = smem;                          // MAXP*64 rows (rows >= NP are written with zeros, never read)
-    char* const dyt = smem + (size_t)MAXP * 64 * XP;
+    char* const dyt = smem + (size_t)MAXP * 64 * XP;  // (PIPE: buffer b = [halo | dY] at smem + b * BUF)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const int piece = tid & 3;
@@ -151,10 +177,11 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
         const int pw = pp & (p.TW - 1), ph = (pp >> p.lgTW) & (p.TH - 1), pd = pp >> (p.lgTW + p.lgTH);
         return ((pd * p.IH + ph * p.sh) * p.IW + pw * p.sw) * XP + colb * 2;
     };
-    int xrow[KEEP_REL ? NKS : 1][2];
+    constexpr bool DMA = PIPE && !PRE;                 // double-buffered LDS-DMA path (below)
+    int xrow[(KEEP_REL && !DMA) ? NKS : 1][2];
     int arow[MT];                                      // dY fragment base of this lane (k-step 0, t = 0)
     if constexpr (IS_BF16) {
-        if constexpr (KEEP_REL) {
+        if constexpr (KEEP_REL && !DMA) {
 #pragma unroll
             for (int j = 0; j < NKS; ++j)
 #pragma unroll
@@ -233,7 +260,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
 #pragma unroll
         for (int i = decltype(LO)::value; i < decltype(HI)::value; ++i) {
             uint4 u = xpos[i] >= 0 ? xv[i] : make_uint4(0u, 0u, 0u, 0u);
-            if (p.pre_a != nullptr) {
+            if constexpr (PRE) {
                 if (xpos[i] >= 0) {
                     const int smp = (KD == 3) ? n_cur : (int)((unsigned)xpos[i] / (unsigned)p.S_in);
                     const size_t co = (size_t)smp * p.cin + c + piece * PE;
@@ -267,80 +294,218 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     using IH = std::integral_constant<int, MAXP / 2>;
     using IM = std::integral_constant<int, MAXP>;
 
-    constexpr bool PF = (MAXP <= 10);      // big-halo (strided) variant: no cross-tile prefetch, it would spill
-    if (PF && tile0 < tile1) {
-        decode(tile0);
-        issue_x(I0{}, IM{});
-        issue_dy();
-    }
-    for (int tl = tile0; tl < tile1; ++tl) {
-        if constexpr (PF) {
-            __syncthreads();   // previous tile's fragments consumed
-            store_x(I0{}, IM{});
-            store_dy();
+    if constexpr (DMA) {
+        // ------------------------------------------------------------------ double-buffered LDS tiles filled by LDS-DMA
+        // Phase of tile t: (1) issue the 18 global_load_lds_dwordx4 of tile t+1 into the other buffer (addresses were computed
+        // during phase t-1), (2) compute the addresses of tile t+2 (pure VALU, blended into the MFMAs by the compiler),
+        // (3) 16 k-steps of MFMAs out of this tile's buffer, (4) __syncthreads(): its vmcnt(0) retires the DMA, its barrier
+        // publishes the buffer.  No staging registers, no ds_write, no serial load-wait / write / set-up phase per tile.
+        // The LDS image is lane-linear (16 bytes x tid per 4 KB slot), which is exactly the halo layout (64-byte rows, 4 pieces)
+        // and the dY layout (128-byte rows, 8 pieces); the dY half-swap of rows with bit 1 set and the zero fill of padding /
+        // out-of-range rows are applied on the SOURCE side (swapped channel piece; a zero page in the code object).
+        const int dsw = dpiece ^ (((tid >> 4) & 1) << 2);                  // channel piece this thread FETCHES for its dY slots
+        const bool dsw_ok = (co0 + dsw * PE) < p.dyw;
+        const char* const dsrc2 = p.dy + (size_t)(dsw_ok ? co0 + dsw * PE : 0) * sizeof(T);
+        const char* const zpage = reinterpret_cast<const char*>(g_wgrad_zero);
+        const char* ax[MAXP];
+        const char* ad[8];
+        int od_lim = 0, oh_lim = 0, ow_lim = 0;
+        // LDS row offset of position pp of the tile = sum over the set bits k of pp of C_k (the pw / ph / pd fields are disjoint bit
+        // ranges of pp): xrow_of(j, tt) = xb[tt] + sum of kc[] over the bits of j.  kc[] is wave-uniform (scalar registers), so the
+        // 32 per-k-step row offsets of the single-buffered path shrink to two vector registers.
+        auto bitc = [&](int k) {
+            return (k < p.lgTW ? (p.sw << k) : k < p.lgTW + p.lgTH ? (p.sh * p.IW) << (k - p.lgTW) : (p.IH * p.IW) << (k - p.lgTW - p.lgTH)) * XP;
+        };
+        int kc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) kc[k] = bitc(4 + k);
+        int xb[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) xb[tt] = xrow_of(0, tt);          // j = 0: the lane's part (+ the wave's k-step base if !TAPSPLIT)
+
+        auto decode2 = [&](int tl) {                                       // wave-uniform part (scalar unit)
+            decode(tl);
+            od_lim = p.Do - (gd_base + KD / 2);
+            oh_lim = p.Ho - (gh_base + KH / 2) / p.sh;
+            ow_lim = p.Wo - (gw_base + KW / 2) / p.sw;
+        };
+        auto addr_slot = [&](auto SL) {                                    // global source of slot SL of the tile last decoded
+            constexpr int sl = decltype(SL)::value;
+            if constexpr (sl < MAXP) {
+                constexpr int i = sl;
+                const int id = sdec[i] >> 20, ih = (sdec[i] >> 10) & 1023, iw = sdec[i] & 1023;
+                const bool ok = (sdec[i] >= 0) & ((unsigned)(gd_base + id) < (unsigned)p.D) & ((unsigned)(gh_base + ih) < (unsigned)p.H) &
+                                ((unsigned)(gw_base + iw) < (unsigned)p.W);
+                ax[i] = ok ? src + (size_t)(base + srel[i]) * cs * sizeof(T) : zpage;
+            } else {
+                constexpr int i = sl - MAXP;
+                const int pd = ddec[i] >> 20, ph = (ddec[i] >> 10) & 1023, pw = ddec[i] & 1023;
+                const bool ok = (pd < od_lim) & (ph < oh_lim) & (pw < ow_lim) & dsw_ok;
+                ad[i] = ok ? dsrc2 + (size_t)(dbase + drel[i]) * p.dyw * sizeof(T) : zpage;
+            }
+        };
+        constexpr int NSLOT = MAXP + 8;
+        auto addresses = [&](int tl) {
+            decode2(tl);
+            static_for<NSLOT>([&](auto SL) { addr_slot(SL); });
+        };
+        // LDS-DMA as inline asm (cdna_hip_programming.md 5.7): through the builtin the compiler treats the DMA as a store that may
+        // alias every later ds_read and drains vmcnt(0) in front of the first fragment read of the phase - the whole HBM -> LDS
+        // latency serial again.  As asm it is invisible to the compiler's wait bookkeeping; the one wait it needs (all of them
+        // landed before the buffer is published) is the explicit vmcnt(0) in front of the end-of-phase barrier below.
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+        auto glds16 = [&](const char* gsrc, unsigned lds_dst) {
+            unsigned keep;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+        };
+        auto dma = [&](int wb) {                                           // wave-uniform LDS base + 16 bytes x lane
+            static_for<MAXP>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                glds16(ax[i], lds0 + wb + wave * 1024 + i * 4096);
+            });
+            static_for<8>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                glds16(ad[i], lds0 + wb + XBUF + wave * 1024 + i * 4096);
+            });
+        };
+        if (tile0 < tile1) {
+            addresses(tile0);
+            dma(0);
+            addresses(min(tile0 + 1, tile1 - 1));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            // next tile's loads fly under this tile's MFMAs (last: harmless re-read)
-            decode(min(tl + 1, tile1 - 1));
+        }
+        for (int tl = tile0; tl < tile1; ++tl) {
+            const int rdb = ((tl - tile0) & 1) * BUF, wrb = BUF - rdb;
+            dma(wrb);                                       // tile tl + 1 (past the end: a harmless re-read of the last tile)
+            decode2(min(tl + 2, tile1 - 1));                // its slot addresses are dealt into the k-steps below
+            int tob[TPW], ab[MT];
+#pragma unroll
+            for (int ti = 0; ti < TPW; ++ti) tob[ti] = tapoff[ti] + rdb;
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) ab[mi] = arow[mi] + rdb + XBUF;
+            // Fragments of k-step j + 1 are read from LDS BEFORE the 14 MFMAs of k-step j are issued (two register sets): with one
+            // wave per SIMD nothing else covers the ~100+ cycles of a transposing read.
+            uint4 fa[2][MT], fb[2][TPW];
+            auto rd_frags = [&](auto J) {
+                constexpr int j = decltype(J)::value;
+                constexpr int s_ = j & 1;
+                const int sj = ((j & 1) ? kc[0] : 0) + ((j & 2) ? kc[1] : 0) + ((j & 4) ? kc[2] : 0) + ((j & 8) ? kc[3] : 0);   // scalar
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) fa[s_][mi] = tr_frag(smem, ab[mi] + j * 16 * DYP, ab[mi] + (j * 16 + 4) * DYP);
+#pragma unroll
+                for (int ti = 0; ti < TPW; ++ti) fb[s_][ti] = tr_frag(smem, xb[0] + (tob[ti] + sj), xb[1] + (tob[ti] + sj));
+            };
+            rd_frags(std::integral_constant<int, 0>{});
+            static_for<NKS>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                if constexpr (j + 1 < NKS) rd_frags(std::integral_constant<int, j + 1>{});
+#pragma unroll
+                for (int ti = 0; ti < TPW; ++ti)
+#pragma unroll
+                    for (int mi = 0; mi < MT; ++mi) mma_step<T>(fa[j & 1][mi], fb[j & 1][ti], acc[ti][mi]);
+                // this k-step's share of the address set-up of tile tl + 2 (pure VALU, hidden under the MFMAs)
+                static_for<NSLOT>([&](auto SL) {
+                    if constexpr ((decltype(SL)::value * NKS) / NSLOT == j) addr_slot(SL);
+                });
+            });
+            if (do_bias) {
+                // bias gradient = channel sums of dY: this thread's 8 pieces of the tile just reduced (LDS slot tid * 16 of
+                // each 4 KB dY slot holds channel piece dsw); only the workgroups of input-channel chunk 0 (uniform branch)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint4 u = *reinterpret_cast<const uint4*>(smem + rdb + XBUF + tid * 16 + i * 4096);
+                    bsum[0] += __uint_as_float(u.x << 16); bsum[1] += __uint_as_float(u.x & 0xFFFF0000u);
+                    bsum[2] += __uint_as_float(u.y << 16); bsum[3] += __uint_as_float(u.y & 0xFFFF0000u);
+                    bsum[4] += __uint_as_float(u.z << 16); bsum[5] += __uint_as_float(u.z & 0xFFFF0000u);
+                    bsum[6] += __uint_as_float(u.w << 16); bsum[7] += __uint_as_float(u.w & 0xFFFF0000u);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile tl + 1 have landed ...
+            __syncthreads();                                   // ... everyone's have; and buffer rdb is free
+        }
+    } else {
+        constexpr bool PF = (MAXP <= 10);      // big-halo (strided) variant: no cross-tile prefetch, it would spill
+        if (PF && tile0 < tile1) {
+            decode(tile0);
             issue_x(I0{}, IM{});
             issue_dy();
-        } else {
-            decode(tl);
-            issue_x(I0{}, IH{});
-            issue_dy();
-            __syncthreads();
-            store_x(I0{}, IH{});
-            store_dy();
-            issue_x(IH{}, IM{});
-            store_x(IH{}, IM{});
-            __syncthreads();
+        }
+        for (int tl = tile0; tl < tile1; ++tl) {
+            if constexpr (PF) {
+                __syncthreads();   // previous tile's fragments consumed
+                store_x(I0{}, IM{});
+                store_dy();
+                __syncthreads();
+                // next tile's loads fly under this tile's MFMAs (last: harmless re-read)
+                decode(min(tl + 1, tile1 - 1));
+                issue_x(I0{}, IM{});
+                issue_dy();
+            } else {
+                decode(tl);
+                issue_x(I0{}, IH{});
+                issue_dy();
+                __syncthreads();
+                store_x(I0{}, IH{});
+                store_dy();
+                issue_x(IH{}, IM{});
+                store_x(IH{}, IM{});
+                __syncthreads();
+            }
+
+            // ---- reduce this tile's positions
+            if constexpr (IS_BF16) {
+                auto kstep = [&](int j, int xr0, int xr1) {
+                    uint4 a[MT];
+    #pragma unroll
+                    for (int mi = 0; mi < MT; ++mi) a[mi] = tr_frag(dyt, arow[mi] + j * 16 * DYP, arow[mi] + (j * 16 + 4) * DYP);
+    #pragma unroll
+                    for (int ti = 0; ti < TPW; ++ti) {
+                        const uint4 b = tr_frag(halo, xr0 + tapoff[ti], xr1 + tapoff[ti]);
+    #pragma unroll
+                        for (int mi = 0; mi < MT; ++mi) mma_step<T>(a[mi], b, acc[ti][mi]);
+                    }
+                };
+                if constexpr (KEEP_REL) {
+    #pragma unroll
+                    for (int j = 0; j < NKS; ++j) kstep(j, xrow[j][0], xrow[j][1]);
+                } else {
+    #pragma unroll 2
+                    for (int j = 0; j < NKS; ++j) kstep(j, xrow_of(j, 0), xrow_of(j, 1));   // rolled: keeps the decode out of registers
+                }
+            } else {
+                // exact f32: k = position pair (2*kk + half); lanes with ci >= 16 contribute zeros
+                const int kk0 = TAPSPLIT ? 0 : wave * 32;
+                const int kk1 = TAPSPLIT ? 128 : wave * 32 + 32;
+                const int col = lane & 31;
+                for (int kk = kk0; kk < kk1; ++kk) {
+                    const int pp = 2 * kk + half;
+                    const int pw = pp & (p.TW - 1), ph = (pp >> p.lgTW) & (p.TH - 1), pd = pp >> (p.lgTW + p.lgTH);
+                    const float av = *reinterpret_cast<const float*>(dyt + pp * DYP + ((col * 4) ^ dy_swz(pp)));
+                    const int xr = ((pd * p.IH + ph * p.sh) * p.IW + pw * p.sw) * XP + (col & 15) * 4;
+    #pragma unroll
+                    for (int ti = 0; ti < TPW; ++ti) {
+                        float bv = *reinterpret_cast<const float*>(halo + xr + tapoff[ti]);
+                        bv = (col < 16) ? bv : 0.0f;
+                        acc[ti][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[ti][0], 0, 0, 0);
+                    }
+                }
+            }
         }
 
-        // ---- reduce this tile's positions
-        if constexpr (IS_BF16) {
-            auto kstep = [&](int j, int xr0, int xr1) {
-                uint4 a[MT];
-#pragma unroll
-                for (int mi = 0; mi < MT; ++mi) a[mi] = tr_frag(dyt, arow[mi] + j * 16 * DYP, arow[mi] + (j * 16 + 4) * DYP);
-#pragma unroll
-                for (int ti = 0; ti < TPW; ++ti) {
-                    const uint4 b = tr_frag(halo, xr0 + tapoff[ti], xr1 + tapoff[ti]);
-#pragma unroll
-                    for (int mi = 0; mi < MT; ++mi) mma_step<T>(a[mi], b, acc[ti][mi]);
-                }
-            };
-            if constexpr (KEEP_REL) {
-#pragma unroll
-                for (int j = 0; j < NKS; ++j) kstep(j, xrow[j][0], xrow[j][1]);
-            } else {
-#pragma unroll 2
-                for (int j = 0; j < NKS; ++j) kstep(j, xrow_of(j, 0), xrow_of(j, 1));   // rolled: keeps the decode out of registers
-            }
-        } else {
-            // exact f32: k = position pair (2*kk + half); lanes with ci >= 16 contribute zeros
-            const int kk0 = TAPSPLIT ? 0 : wave * 32;
-            const int kk1 = TAPSPLIT ? 128 : wave * 32 + 32;
-            const int col = lane & 31;
-            for (int kk = kk0; kk < kk1; ++kk) {
-                const int pp = 2 * kk + half;
-                const int pw = pp & (p.TW - 1), ph = (pp >> p.lgTW) & (p.TH - 1), pd = pp >> (p.lgTW + p.lgTH);
-                const float av = *reinterpret_cast<const float*>(dyt + pp * DYP + ((col * 4) ^ dy_swz(pp)));
-                const int xr = ((pd * p.IH + ph * p.sh) * p.IW + pw * p.sw) * XP + (col & 15) * 4;
-#pragma unroll
-                for (int ti = 0; ti < TPW; ++ti) {
-                    float bv = *reinterpret_cast<const float*>(halo + xr + tapoff[ti]);
-                    bv = (col < 16) ? bv : 0.0f;
-                    acc[ti][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[ti][0], 0, 0, 0);
-                }
-            }
-        }
     }
 
     // ---- bias gradient: threads tid = dpiece (mod 8) hold sums of the same channels -> LDS -> one atomic per channel
     if (do_bias) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);               // [256][DPE]
+        // (LDS-DMA path: this thread summed channel piece dpiece ^ 4 when bit 1 of its dY rows is set - the half-swap lives on the
+        //  source side there; slot it under the piece it really holds)
+        const int bslot = DMA ? ((tid & ~7) | (dpiece ^ (((tid >> 4) & 1) << 2))) : tid;
 #pragma unroll
-        for (int e = 0; e < DPE; ++e) red[tid * DPE + e] = bsum[e];
+        for (int e = 0; e < DPE; ++e) red[bslot * DPE + e] = bsum[e];
         __syncthreads();
         if (tid < 8 * DPE) {
             const int piece = tid / DPE, e = tid % DPE;
@@ -510,27 +675,22 @@ thread_local VariantOut* g_wvariant = nullptr;      // see rho_conv_variant (con
 template <typename T, int KD, int KH, int KW>
 int launch_wgrad(const WgradK& k, int maxp, dim3 grid, size_t lds, hipStream_t st) {
     if (g_wvariant != nullptr) {
-        snprintf(g_wvariant->buf, (size_t)g_wvariant->cap, "k_wgrad<%s,%d,%d,%d,MAXP=%d>", sizeof(T) == 2 ? "bf16" : "f32", KD, KH, KW,
-                 maxp <= 10 ? 10 : 28);
+        snprintf(g_wvariant->buf, (size_t)g_wvariant->cap, "k_wgrad<%s,%d,%d,%d,MAXP=%d,PRE=%d>", sizeof(T) == 2 ? "bf16" : "f32", KD, KH,
+                 KW, maxp <= 10 ? 10 : 28, k.pre_a != nullptr ? 1 : 0);
         return 0;
     }
-    if (maxp <= 10) {
-        auto fn = k_wgrad<T, KD, KH, KW, 10>;
+    auto go = [&](auto fn) -> int {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
         }
         hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, k);
-    } else {
-        auto fn = k_wgrad<T, KD, KH, KW, 28>;
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return (int)e;
-        }
-        hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, k);
-    }
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : (int)e;
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : (int)e;
+    };
+    const bool pre = k.pre_a != nullptr;
+    if (maxp <= 10) return pre ? go(k_wgrad<T, KD, KH, KW, 10, true>) : go(k_wgrad<T, KD, KH, KW, 10, false>);
+    return pre ? go(k_wgrad<T, KD, KH, KW, 28, true>) : go(k_wgrad<T, KD, KH, KW, 28, false>);
 }
 
 template <typename T>
@@ -656,7 +816,8 @@ static int wgrad_impl(const rho_conv_desc* dp, const void* dy, int64_t dy_width,
     if (cdiv(d.coutp, COT) > 65535 || cin / CK > 65535) return RHO_E_SHAPE;
     dim3 grid((unsigned)splits, (unsigned)cdiv(d.coutp, COT), (unsigned)(cin / CK));
     const int maxp = cdiv(t.NP, 64);
-    const size_t lds = (size_t)(maxp <= 10 ? 10 : 28) * 64 * XP + 256 * DYP;
+    size_t lds = (size_t)(maxp <= 10 ? 10 : 28) * 64 * XP + 256 * DYP;
+    if (d.dtype == RHO_BF16 && maxp <= 10 && !d.pre_a) lds *= 2;     // LDS-DMA path: double-buffered tiles (2 x 72 KB)
     hipStream_t st = as_stream(stream);
     if (d.dtype == RHO_BF16) return launch_wgrad_taps<bf16_raw>(d, k, maxp, grid, lds, st);
     return launch_wgrad_taps<float>(d, k, maxp, grid, lds, st);

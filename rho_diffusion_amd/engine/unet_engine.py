@@ -371,6 +371,7 @@ class _Plan:
         self.eng = eng
         self.train = train
         self.materialize_act = os.environ.get("RHO_TRAIN_MATERIALIZE", "1") != "0"    # memory-for-time trade of training plans
+        self.materialize_min_cout = int(os.environ.get("RHO_MATERIALIZE_MIN_COUT", "256"))
         m = eng.model
         dt = eng.dtype
         dtc = hip.dtype_code(dt)
@@ -477,7 +478,11 @@ class _Plan:
             # 1x1x1 projections with many cout tiles (the attention qkv: 12 tiles of 128) redo the prologue per tile with
             # nothing to hide it under (probe: 0.70 ms with, 0.43 ms without, for 0.06 ms of materialising pass)
             wide_1x1 = cw.taps == 1 and cout >= 512
-            if pre is not None and up_hw == (0, 0) and ((self.train and self.materialize_act) or wide_1x1):
+            # 3x3(x3) convs with >= 2 cout tiles of 128 (the 256- and 512-wide levels): every cout tile redoes GroupNorm + SiLU on the
+            # halo tile it stages (2.5x the input per tile): 8.5 % of the launch against a 0.05 ms pass that applies it once
+            # (tools/ab_conv.py, "+pre" rows; only where the tensor is small enough that the extra pass costs less than the prologue)
+            wide_3x3 = (cw.taps > 1 and cout >= self.materialize_min_cout and dt == torch.bfloat16)
+            if pre is not None and up_hw == (0, 0) and ((self.train and self.materialize_act) or wide_1x1 or wide_3x3):
                 # training: the activated input act(a*x+b) is needed twice (this conv, its weight gradient) and the conv
                 # loader would recompute it 2.3x (halo) per cout tile: materialise it once (one HBM-rate pass, kept for
                 # backward: +1 activation-sized buffer per normalised conv, 38 GB at c3) and feed both from it
