@@ -346,6 +346,14 @@ int rho_upsample2x(const void* x, void* y, int dtype, int64_t n_times_d, int64_t
 int rho_pool2x_sum(const void* dy, void* dx, int dtype, int64_t n_times_d, int64_t h, int64_t w, int64_t c, int up_h,
                    int up_w, int accumulate, void* stream);
 
+/* avg_pool_nd with kernel = stride = 2 on H and / or W (layers.py:91-102; Downsample of conv_resample = False, unet_v2.py:165, and the
+ * h_upd / x_upd of ResBlock(down = True), :221-224), channels-last, output extents floor(h / 2), floor(w / 2). */
+int rho_avgpool2x(const void* x, void* y, int dtype, int64_t n_times_d, int64_t h, int64_t w, int64_t c, int pool_h, int pool_w,
+                  void* stream);
+/* its backward: dx [.., h, w, c] (+)= dy[.., h / 2, w / 2, c] / window; rows / columns dropped by the floor receive zero. */
+int rho_avgpool2x_bwd(const void* dy, void* dx, int dtype, int64_t n_times_d, int64_t h, int64_t w, int64_t c, int pool_h, int pool_w,
+                      int accumulate, void* stream);
+
 /* Backward of rho_linear: dw[o,k] (+)= sum_b dout[b,o] act(x[b,k]); db[o] (+)= sum_b dout[b,o];
  * dx[b,k] (+)= act'(x[b,k]) sum_o dout[b,o] w[o,k].  dw/db/dx may be NULL; dout rows are dout_stride floats apart
  * (0 = out_dim) so a slice of the batched FiLM gradient can be passed in place. */

@@ -111,11 +111,22 @@ def upsample(dims: int, x: Tensor) -> Tensor:
     return F.interpolate(x, scale_factor=2, mode="nearest")
 
 
+def avg_pool(dims: int, x: Tensor) -> Tensor:
+    """rho_diffusion/models/unet_v2.py:153,165 (Downsample without conv): avg_pool_nd(kernel = stride = 2; 3-D: (1, 2, 2))."""
+    if dims == 3:
+        return F.avg_pool3d(x, (1, 2, 2), (1, 2, 2))
+    return {1: F.avg_pool1d, 2: F.avg_pool2d}[dims](x, 2, 2)
+
+
 def resblock(dims: int, x: Tensor, emb: Tensor, sd: Dict[str, Tensor], p: str,
-             use_scale_shift_norm: bool) -> Tensor:
-    """rho_diffusion/models/unet_v2.py:273-293 (ResBlock._forward, no up/down, dropout 0)."""
-    h = group_norm32(x, sd[p + "in_layers.0.weight"], sd[p + "in_layers.0.bias"])
-    h = conv_nd(dims, F.silu(h), sd[p + "in_layers.2.weight"], sd[p + "in_layers.2.bias"], padding=1)
+             use_scale_shift_norm: bool, updown: Optional[str] = None) -> Tensor:
+    """rho_diffusion/models/unet_v2.py:273-293 (ResBlock._forward, dropout 0).  updown = "up" / "down": the activated input and
+    the skip input are resampled before the first conv (:277-281; Upsample / Downsample without conv, :221-224)."""
+    h = F.silu(group_norm32(x, sd[p + "in_layers.0.weight"], sd[p + "in_layers.0.bias"]))
+    if updown is not None:
+        rs = (lambda v: upsample(dims, v)) if updown == "up" else (lambda v: avg_pool(dims, v))
+        h, x = rs(h), rs(x)
+    h = conv_nd(dims, h, sd[p + "in_layers.2.weight"], sd[p + "in_layers.2.bias"], padding=1)
     emb_out = F.linear(F.silu(emb), sd[p + "emb_layers.1.weight"], sd[p + "emb_layers.1.bias"]).type(h.dtype)
     while emb_out.dim() < h.dim():
         emb_out = emb_out[..., None]
@@ -168,8 +179,7 @@ def attention_block(x: Tensor, sd: Dict[str, Tensor], p: str, n_heads: int, new_
 def unet_structure(cfg: dict) -> dict:
     """Replays the constructor loops of rho_diffusion/models/unet_v2.py:533-683 and returns,
     per ``input_blocks`` / ``middle_block`` / ``output_blocks`` entry, the list of layer kinds
-    with their ``state_dict`` prefixes.  Supported: conv_resample=True, resblock_updown=False
-    (every shipped config)."""
+    with their ``state_dict`` prefixes (incl. resblock_updown = True and conv_resample = False, :575-590, :655-675)."""
     mc = cfg["model_channels"]
     mult = tuple(cfg.get("channel_mult", (1, 2, 4, 8)))
     nres = cfg["num_res_blocks"]
@@ -179,7 +189,8 @@ def unet_structure(cfg: dict) -> dict:
     heads_up = cfg.get("num_heads_upsample", -1)
     if heads_up == -1:
         heads_up = heads
-    assert cfg.get("conv_resample", True) and not cfg.get("resblock_updown", False)
+    conv_resample = bool(cfg.get("conv_resample", True))
+    updown = bool(cfg.get("resblock_updown", False))
 
     def nh(c, h):
         return h if nhc == -1 else c // nhc
@@ -199,7 +210,10 @@ def unet_structure(cfg: dict) -> dict:
             chans.append(ch)
         if level != len(mult) - 1:
             idx = len(inp)
-            inp.append([("down", f"input_blocks.{idx}.0.op.", ch)])
+            if updown:
+                inp.append([("res_down", f"input_blocks.{idx}.0.", ch, ch)])
+            else:
+                inp.append([("down" if conv_resample else "pool", f"input_blocks.{idx}.0.op.", ch)])
             chans.append(ch)
             ds *= 2
     mid = [("res", "middle_block.0.", ch, ch), ("attn", "middle_block.1.", ch, nh(ch, heads)),
@@ -214,7 +228,10 @@ def unet_structure(cfg: dict) -> dict:
             if ds in attn_res:
                 layers.append(("attn", f"output_blocks.{idx}.{len(layers)}.", ch, nh(ch, heads_up)))
             if level and i == nres:
-                layers.append(("up", f"output_blocks.{idx}.{len(layers)}.conv.", ch))
+                if updown:
+                    layers.append(("res_up", f"output_blocks.{idx}.{len(layers)}.", ch, ch))
+                else:
+                    layers.append(("up" if conv_resample else "up_only", f"output_blocks.{idx}.{len(layers)}.conv.", ch))
                 ds //= 2
             out.append(layers)
     return {"input": inp, "middle": mid, "output": out, "final_ch": ch}
@@ -229,6 +246,12 @@ def _run_layers(dims, layers, h, emb, sd, cfg):
             h = conv_nd(dims, h, sd[p + "weight"], sd[p + "bias"], padding=1)
         elif kind == "res":
             h = resblock(dims, h, emb, sd, p, ssn)
+        elif kind in ("res_up", "res_down"):
+            h = resblock(dims, h, emb, sd, p, ssn, updown=kind[4:])
+        elif kind == "pool":
+            h = avg_pool(dims, h)
+        elif kind == "up_only":
+            h = upsample(dims, h)
         elif kind == "attn":
             h = attention_block(h, sd, p, layer[3], new_order)
         elif kind == "down":

@@ -637,6 +637,135 @@ extern "C" int rho_pool2x_sum(const void* dy, void* dx, int dtype, int64_t n_tim
     return 0;
 }
 
+// ----------------------------------------------------------------------------- average pooling (K12)
+// avg_pool_nd(dims, kernel_size = stride, stride = stride), stride 2 (3-D: (1, 2, 2)), layers.py:91-102 / unet_v2.py:165: the
+// Downsample of conv_resample = False and of ResBlock(down = True).  Channels-last, one 16-byte channel piece per thread;
+// output extent floor(h / 2) (PyTorch's ceil_mode = False: an odd last row / column is dropped).
+template <typename T>
+__global__ __launch_bounds__(256) void k_avgpool2x(const T* __restrict__ x, T* __restrict__ y, int64_t nd, int h, int w, int c, int fh,
+                                                   int fw) {
+    constexpr int PE = 16 / (int)sizeof(T);
+    const int ho = fh ? h >> 1 : h, wo = fw ? w >> 1 : w;
+    const int cp = c / PE;
+    const float scale = 1.0f / (float)((fh ? 2 : 1) * (fw ? 2 : 1));
+    const int64_t total = nd * ho * wo * cp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int pc = (int)(i % cp);
+        int64_t r = i / cp;
+        const int ow = (int)(r % wo); r /= wo;
+        const int oh = (int)(r % ho); r /= ho;
+        float acc[PE];
+#pragma unroll
+        for (int e = 0; e < PE; ++e) acc[e] = 0.0f;
+        for (int a = 0; a <= fh; ++a)
+            for (int b = 0; b <= fw; ++b) {
+                const int64_t o = ((r * h + (fh ? 2 * oh + a : oh)) * w + (fw ? 2 * ow + b : ow)) * c + pc * PE;
+                const uint4 u = *reinterpret_cast<const uint4*>(x + o);
+                if constexpr (sizeof(T) == 2) {
+                    acc[0] += __uint_as_float(u.x << 16); acc[1] += __uint_as_float(u.x & 0xFFFF0000u);
+                    acc[2] += __uint_as_float(u.y << 16); acc[3] += __uint_as_float(u.y & 0xFFFF0000u);
+                    acc[4] += __uint_as_float(u.z << 16); acc[5] += __uint_as_float(u.z & 0xFFFF0000u);
+                    acc[6] += __uint_as_float(u.w << 16); acc[7] += __uint_as_float(u.w & 0xFFFF0000u);
+                } else {
+                    acc[0] += __uint_as_float(u.x); acc[1] += __uint_as_float(u.y); acc[2] += __uint_as_float(u.z); acc[3] += __uint_as_float(u.w);
+                }
+            }
+        T* dst = y + (i / cp) * c + pc * PE;
+        if constexpr (sizeof(T) == 2)
+            *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(acc[0] * scale, acc[1] * scale), pack_bf16x2(acc[2] * scale, acc[3] * scale),
+                                                        pack_bf16x2(acc[4] * scale, acc[5] * scale), pack_bf16x2(acc[6] * scale, acc[7] * scale));
+        else
+            *reinterpret_cast<uint4*>(dst) = make_uint4(__float_as_uint(acc[0] * scale), __float_as_uint(acc[1] * scale),
+                                                        __float_as_uint(acc[2] * scale), __float_as_uint(acc[3] * scale));
+    }
+}
+
+extern "C" int rho_avgpool2x(const void* x, void* y, int dtype, int64_t n_times_d, int64_t h, int64_t w, int64_t c, int pool_h, int pool_w,
+                             void* stream) {
+    if (!x || !y || n_times_d <= 0 || h <= 0 || w <= 0 || c <= 0 || (pool_h && h < 2) || (pool_w && w < 2)) return RHO_E_ARG;
+    if (dtype != RHO_BF16 && dtype != RHO_F32) return RHO_E_ARG;
+    const int pe = dtype == RHO_BF16 ? 8 : 4;
+    if (c % pe != 0) return RHO_E_ALIGN;
+    const int64_t total = n_times_d * (pool_h ? h / 2 : h) * (pool_w ? w / 2 : w) * (c / pe);
+    dim3 grid(grid_for(total, 256)), block(256);
+    if (dtype == RHO_BF16)
+        hipLaunchKernelGGL(k_avgpool2x<bf16_raw>, grid, block, 0, as_stream(stream), (const bf16_raw*)x, (bf16_raw*)y, n_times_d, (int)h, (int)w,
+                           (int)c, pool_h, pool_w);
+    else
+        hipLaunchKernelGGL(k_avgpool2x<float>, grid, block, 0, as_stream(stream), (const float*)x, (float*)y, n_times_d, (int)h, (int)w, (int)c,
+                           pool_h, pool_w);
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
+// backward: dx[.., ih, iw, :] (+)= dy[.., ih / 2, iw / 2, :] / (window size); rows / columns the pooling dropped receive 0
+template <typename T>
+__global__ __launch_bounds__(256) void k_avgpool2x_bwd(const T* __restrict__ dy, T* __restrict__ dx, int64_t nd, int h, int w, int c, int fh,
+                                                       int fw, int accumulate) {
+    constexpr int PE = 16 / (int)sizeof(T);
+    const int ho = fh ? h >> 1 : h, wo = fw ? w >> 1 : w;
+    const int cp = c / PE;
+    const float scale = 1.0f / (float)((fh ? 2 : 1) * (fw ? 2 : 1));
+    const int64_t total = nd * h * w * cp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int pc = (int)(i % cp);
+        int64_t r = i / cp;
+        const int iw = (int)(r % w); r /= w;
+        const int ih = (int)(r % h); r /= h;
+        const int oh = fh ? ih >> 1 : ih, ow = fw ? iw >> 1 : iw;
+        float acc[PE];
+#pragma unroll
+        for (int e = 0; e < PE; ++e) acc[e] = 0.0f;
+        if (oh < ho && ow < wo) {
+            const uint4 u = *reinterpret_cast<const uint4*>(dy + ((r * ho + oh) * wo + ow) * c + pc * PE);
+            if constexpr (sizeof(T) == 2) {
+                acc[0] = __uint_as_float(u.x << 16) * scale; acc[1] = __uint_as_float(u.x & 0xFFFF0000u) * scale;
+                acc[2] = __uint_as_float(u.y << 16) * scale; acc[3] = __uint_as_float(u.y & 0xFFFF0000u) * scale;
+                acc[4] = __uint_as_float(u.z << 16) * scale; acc[5] = __uint_as_float(u.z & 0xFFFF0000u) * scale;
+                acc[6] = __uint_as_float(u.w << 16) * scale; acc[7] = __uint_as_float(u.w & 0xFFFF0000u) * scale;
+            } else {
+                acc[0] = __uint_as_float(u.x) * scale; acc[1] = __uint_as_float(u.y) * scale;
+                acc[2] = __uint_as_float(u.z) * scale; acc[3] = __uint_as_float(u.w) * scale;
+            }
+        }
+        T* dst = dx + (i / cp) * c + pc * PE;
+        if (accumulate) {
+            const uint4 u = *reinterpret_cast<const uint4*>(dst);
+            if constexpr (sizeof(T) == 2) {
+                acc[0] += __uint_as_float(u.x << 16); acc[1] += __uint_as_float(u.x & 0xFFFF0000u);
+                acc[2] += __uint_as_float(u.y << 16); acc[3] += __uint_as_float(u.y & 0xFFFF0000u);
+                acc[4] += __uint_as_float(u.z << 16); acc[5] += __uint_as_float(u.z & 0xFFFF0000u);
+                acc[6] += __uint_as_float(u.w << 16); acc[7] += __uint_as_float(u.w & 0xFFFF0000u);
+            } else {
+                acc[0] += __uint_as_float(u.x); acc[1] += __uint_as_float(u.y); acc[2] += __uint_as_float(u.z); acc[3] += __uint_as_float(u.w);
+            }
+        }
+        if constexpr (sizeof(T) == 2)
+            *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]),
+                                                        pack_bf16x2(acc[6], acc[7]));
+        else
+            *reinterpret_cast<uint4*>(dst) = make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]),
+                                                        __float_as_uint(acc[3]));
+    }
+}
+
+extern "C" int rho_avgpool2x_bwd(const void* dy, void* dx, int dtype, int64_t n_times_d, int64_t h, int64_t w, int64_t c, int pool_h,
+                                 int pool_w, int accumulate, void* stream) {
+    if (!dy || !dx || n_times_d <= 0 || h <= 0 || w <= 0 || c <= 0 || (pool_h && h < 2) || (pool_w && w < 2)) return RHO_E_ARG;
+    if (dtype != RHO_BF16 && dtype != RHO_F32) return RHO_E_ARG;
+    const int pe = dtype == RHO_BF16 ? 8 : 4;
+    if (c % pe != 0) return RHO_E_ALIGN;
+    dim3 grid(grid_for(n_times_d * h * w * (c / pe), 256)), block(256);
+    if (dtype == RHO_BF16)
+        hipLaunchKernelGGL(k_avgpool2x_bwd<bf16_raw>, grid, block, 0, as_stream(stream), (const bf16_raw*)dy, (bf16_raw*)dx, n_times_d, (int)h,
+                           (int)w, (int)c, pool_h, pool_w, accumulate);
+    else
+        hipLaunchKernelGGL(k_avgpool2x_bwd<float>, grid, block, 0, as_stream(stream), (const float*)dy, (float*)dx, n_times_d, (int)h, (int)w,
+                           (int)c, pool_h, pool_w, accumulate);
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
 // Backward of rho_linear (out = W act(x) + b [+ add]):  dW[o,k] (+)= sum_b dout[b,o] act(x[b,k]),  db[o] (+)= sum_b dout[b,o]
 __global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ dout, const float* __restrict__ x,
                                                       float* __restrict__ dw, float* __restrict__ db, int batch, int in_dim,

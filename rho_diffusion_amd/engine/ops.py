@@ -408,6 +408,22 @@ def upsample2x(x: Tensor, up_hw, out: Optional[Tensor] = None) -> Tensor:
     return out
 
 
+def avgpool2x(x: Tensor, pool_hw, out: Optional[Tensor] = None) -> Tensor:
+    """avg_pool_nd(kernel = stride = 2) over the flagged axes of a channels-last tensor (floor output extents)."""
+    N, D, H, W, Cc = x.shape
+    out = torch.empty(N, D, H // 2 if pool_hw[0] else H, W // 2 if pool_hw[1] else W, Cc, dtype=x.dtype, device=x.device) if out is None else out
+    check(hip.lib().rho_avgpool2x(ptr(x), ptr(out), dtype_code(x.dtype), N * D, H, W, Cc, int(pool_hw[0]), int(pool_hw[1]), stream()),
+          "rho_avgpool2x")
+    return out
+
+
+def avgpool2x_bwd(dy: Tensor, dx: Tensor, pool_hw, accumulate: bool = False) -> Tensor:
+    N, D, H, W, Cc = dx.shape
+    check(hip.lib().rho_avgpool2x_bwd(ptr(dy), ptr(dx), dtype_code(dx.dtype), N * D, H, W, Cc, int(pool_hw[0]), int(pool_hw[1]),
+                                      int(accumulate), stream()), "rho_avgpool2x_bwd")
+    return dx
+
+
 def pool2x_sum(dy: Tensor, dx: Tensor, up_hw, accumulate: bool = False) -> Tensor:
     N, D, H, W, Cc = dx.shape
     check(hip.lib().rho_pool2x_sum(ptr(dy), ptr(dx), dtype_code(dx.dtype), N * D, H, W, Cc, int(up_hw[0]), int(up_hw[1]),

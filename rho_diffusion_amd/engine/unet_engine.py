@@ -230,9 +230,11 @@ class UNetEngine:
                 self._conv(mod.qkv, self._qkv_row_src(mod))
                 self._conv(mod.proj_out)
             elif isinstance(mod, Downsample):
-                self._conv(mod.op)
+                if mod.use_conv:
+                    self._conv(mod.op)
             elif isinstance(mod, Upsample):
-                self._conv(mod.conv)
+                if mod.use_conv:
+                    self._conv(mod.conv)
         self._conv(m.input_blocks[0][0])
         self._conv(m.out[2])
         # FiLM / additive-embedding projections of all ResBlocks, batched into one GEMV launch
@@ -521,7 +523,58 @@ class _Plan:
                                    xact=xact))
             return y, y2
 
+        rs_hw = (1, 1) if dims >= 2 else (0, 1)      # axes a Down/Upsample touches: H and W (3-D: depth stays), 1-D: W only
+
+        def resample(xt, mode):
+            """avg_pool_nd (mode "avg") / nearest x2 (mode "up") of a channels-last tensor as its own pass: the conv-less
+            Down/Upsample of conv_resample = False and the h_upd / x_upd of ResBlock(up / down) (unet_v2.py:122-131,165,221-224)."""
+            N_, Dd, Hh, Ww, Cc = xt.shape
+            if mode == "up":
+                yt = buf(N_, Dd, Hh * 2 if rs_hw[0] else Hh, Ww * 2, Cc)
+                a = (ptr(xt), ptr(yt), dtc, N_ * Dd, Hh, Ww, Cc, rs_hw[0], rs_hw[1])
+                self.ops.append(lambda s, a=a: L.rho_upsample2x(*a, s))
+            else:
+                yt = buf(N_, Dd, Hh // 2 if rs_hw[0] else Hh, Ww // 2, Cc)
+                a = (ptr(xt), ptr(yt), dtc, N_ * Dd, Hh, Ww, Cc, rs_hw[0], rs_hw[1])
+                self.ops.append(lambda s, a=a: L.rho_avgpool2x(*a, s))
+            self.info.append(dict(kind="resample", flops=0.0, bytes=float(esz) * (xt.numel() + yt.numel())))
+            self.nodes.append(dict(k="resample", mode=mode, x=xt, y=yt))
+            return yt
+
+        def activated(x1, x2, pre, pre_silu):
+            """act(a * concat(x1, x2) + b) materialised as a tensor of its own (needed when something other than a conv loader
+            consumes it: the h_upd of an up / down ResBlock resamples AFTER GroupNorm + SiLU, unet_v2.py:277-281)."""
+            c1_ = x1.shape[-1]
+            c2_ = x2.shape[-1] if x2 is not None else 0
+            yt = buf(*x1.shape[:4], c1_ + c2_)
+            Sx = x1.shape[1] * x1.shape[2] * x1.shape[3]
+            ga = (ptr(x1), c1_, ptr(x2), c2_, dtc, x1.shape[0], Sx, ptr(pre["a"]), ptr(pre["b"]), int(pre_silu), ptr(yt))
+            self.ops.append(lambda s, a=ga: L.rho_gn_apply(*a, s))
+            self.info.append(dict(kind="gn_apply", flops=0.0, bytes=2.0 * esz * yt.numel()))
+            self.nodes.append(dict(k="act", x1=x1, x2=x2, pre=pre, pre_silu=pre_silu, y=yt))
+            return yt
+
+        def resblock_updown(blk, h1, h2):
+            from ..models.unet_v2 import Upsample as _Up
+            mode = "up" if isinstance(blk.h_upd, _Up) else "avg"
+            g1 = gn(h1, h2, blk.in_layers[0])
+            hh = resample(activated(h1, h2, g1, True), mode)
+            x1p = resample(h1, mode)
+            x2p = resample(h2, mode) if h2 is not None else None
+            radd = None if blk.use_scale_shift_norm else eng._film_off[id(blk)]
+            t1, _ = conv(hh, None, eng._conv(blk.in_layers[2]), res_add_off=radd)
+            g2 = gn(t1, None, blk.out_layers[0], film_blk=blk if blk.use_scale_shift_norm else None)
+            if isinstance(blk.skip_connection, nn.Identity):
+                assert x2p is None
+                sk = x1p
+            else:
+                sk, _ = conv(x1p, x2p, eng._conv(blk.skip_connection))
+            out, _ = conv(t1, None, eng._conv(blk.out_layers[3]), pre=g2, pre_silu=True, res=sk)
+            return out
+
         def resblock(blk, h1, h2):
+            if getattr(blk, "updown", False):
+                return resblock_updown(blk, h1, h2)
             g1 = gn(h1, h2, blk.in_layers[0])
             radd = None if blk.use_scale_shift_norm else eng._film_off[id(blk)]
             t1, _ = conv(h1, h2, eng._conv(blk.in_layers[2]), pre=g1, pre_silu=True, res_add_off=radd)
@@ -555,11 +608,17 @@ class _Plan:
                 elif isinstance(layer, AttentionBlock):
                     h1 = attention(layer, h1)
                 elif isinstance(layer, Downsample):
-                    st = (2, 2) if dims >= 2 else (1, 2)
-                    h1, _ = conv(h1, None, eng._conv(layer.op), stride_hw=st)
+                    if not layer.use_conv:
+                        h1 = resample(h1, "avg")
+                    else:
+                        st = (2, 2) if dims >= 2 else (1, 2)
+                        h1, _ = conv(h1, None, eng._conv(layer.op), stride_hw=st)
                 elif isinstance(layer, Upsample):
-                    up = (1, 1) if dims >= 2 else (0, 1)
-                    h1, _ = conv(h1, None, eng._conv(layer.conv), up_hw=up)
+                    if not layer.use_conv:
+                        h1 = resample(h1, "up")
+                    else:
+                        up = (1, 1) if dims >= 2 else (0, 1)
+                        h1, _ = conv(h1, None, eng._conv(layer.conv), up_hw=up)
                 else:  # the stem conv
                     h1, _ = conv(h1, None, stem, stem=True)
             return h1
@@ -714,6 +773,43 @@ class _Plan:
             if xact is not None:
                 pool.put(xact)
 
+        def gn_backward(pre, pre_silu, x1, x2, dact):
+            """dact = gradient of act(GroupNorm(x) * (1 + scale) + shift): reduce / finalize / apply into the gradients of x1 (, x2),
+            the norm's parameters and the FiLM rows."""
+            c1 = x1.shape[-1]
+            c2 = x2.shape[-1] if x2 is not None else 0
+            norm = pre["norm"]
+            Cc, N_, S_ = pre["C"], pre["N"], pre["S"]
+            g1, acc1 = gradbuf(x1)
+            g2, acc2 = gradbuf(x2) if x2 is not None else (None, False)
+            cA = pool.get((N_, Cc), torch.float32)
+            cP = pool.get((N_, 32), torch.float32)
+            cQ = pool.get((N_, 32), torch.float32)
+            work = pool.get((2 * N_ * Cc,), torch.float32)
+            scale = dscale = dshift = None
+            fstride = 0
+            if pre["film_off"] is not None:
+                scale = self.film.data_ptr() + 4 * pre["film_off"]
+                fstride = film_stride
+                dscale = self.dfilm.data_ptr() + 4 * pre["film_off"]
+                dshift = self.dfilm.data_ptr() + 4 * (pre["film_off"] + Cc)
+            a1 = (ptr(dact), ptr(x1), c1, ptr(x2), c2, dtc, N_, S_, ptr(pre["a"]), ptr(pre["b"]), ptr(pre["st"]),
+                  int(pre_silu), ptr(pre["part"]))
+            emit(lambda s, a=a1: L.rho_gn_bwd_reduce(*a, s), "gn_bwd_reduce", nbytes=2.0 * esz * N_ * S_ * Cc)
+            emit(lambda s, pre=pre, norm=norm, scale=scale, fstride=fstride, work=work, dscale=dscale, dshift=dshift,
+                 cA=cA, cP=cP, cQ=cQ, N_=N_, Cc=Cc, S_=S_: L.rho_gn_bwd_finalize(
+                     ptr(pre["part"]), N_, Cc, S_, pre["nblk"], ptr(norm.weight), ptr(norm.bias), scale, fstride, ptr(pre["st"]),
+                     ptr(work), pgrad(norm.weight), pgrad(norm.bias), 1, dscale, dshift, film_stride, ptr(cA), ptr(cP),
+                     ptr(cQ), s), "gn_bwd_finalize")
+            a3 = (ptr(dact), ptr(x1), c1, ptr(x2), c2, dtc, N_, S_, ptr(pre["a"]), ptr(pre["b"]), int(pre_silu),
+                  ptr(cA), ptr(cP), ptr(cQ), ptr(g1), ptr(g2), int(acc1), int(acc2))
+            emit(lambda s, a=a3: L.rho_gn_bwd_apply(*a, s), "gn_bwd_apply", nbytes=3.0 * esz * N_ * S_ * Cc)
+            written.add(key(x1))
+            if x2 is not None:
+                written.add(key(x2))
+            for t in (cA, cP, cQ, work):
+                pool.put(t)
+
         def dgrad(node, dY: Tensor, dyw: int):
             cw = node["cw"]
             x1, x2, pre = node["x1"], node["x2"], node["pre"]
@@ -733,37 +829,7 @@ class _Plan:
                 emit(lambda s, d=d: L.rho_conv_nd_fwd(C.byref(d), s), "dgrad",
                      flops=2.0 * (dact.numel() // cin) * cin * cw.cout * cw.taps, nbytes=float(esz) * (dY.numel() + dact.numel()))
                 if pre is not None:
-                    norm = pre["norm"]
-                    Cc, N_, S_ = pre["C"], pre["N"], pre["S"]
-                    g1, acc1 = gradbuf(x1)
-                    g2, acc2 = gradbuf(x2) if x2 is not None else (None, False)
-                    cA = pool.get((N_, Cc), torch.float32)
-                    cP = pool.get((N_, 32), torch.float32)
-                    cQ = pool.get((N_, 32), torch.float32)
-                    work = pool.get((2 * N_ * Cc,), torch.float32)
-                    scale = dscale = dshift = None
-                    fstride = 0
-                    if pre["film_off"] is not None:
-                        scale = self.film.data_ptr() + 4 * pre["film_off"]
-                        fstride = film_stride
-                        dscale = self.dfilm.data_ptr() + 4 * pre["film_off"]
-                        dshift = self.dfilm.data_ptr() + 4 * (pre["film_off"] + Cc)
-                    a1 = (ptr(dact), ptr(x1), c1, ptr(x2), c2, dtc, N_, S_, ptr(pre["a"]), ptr(pre["b"]), ptr(pre["st"]),
-                          int(node["pre_silu"]), ptr(pre["part"]))
-                    emit(lambda s, a=a1: L.rho_gn_bwd_reduce(*a, s), "gn_bwd_reduce", nbytes=2.0 * esz * N_ * S_ * Cc)
-                    emit(lambda s, pre=pre, norm=norm, scale=scale, fstride=fstride, work=work, dscale=dscale, dshift=dshift,
-                         cA=cA, cP=cP, cQ=cQ, N_=N_, Cc=Cc, S_=S_: L.rho_gn_bwd_finalize(
-                             ptr(pre["part"]), N_, Cc, S_, pre["nblk"], ptr(norm.weight), ptr(norm.bias), scale, fstride, ptr(pre["st"]),
-                             ptr(work), pgrad(norm.weight), pgrad(norm.bias), 1, dscale, dshift, film_stride, ptr(cA), ptr(cP),
-                             ptr(cQ), s), "gn_bwd_finalize")
-                    a3 = (ptr(dact), ptr(x1), c1, ptr(x2), c2, dtc, N_, S_, ptr(pre["a"]), ptr(pre["b"]), int(node["pre_silu"]),
-                          ptr(cA), ptr(cP), ptr(cQ), ptr(g1), ptr(g2), int(acc1), int(acc2))
-                    emit(lambda s, a=a3: L.rho_gn_bwd_apply(*a, s), "gn_bwd_apply", nbytes=3.0 * esz * N_ * S_ * Cc)
-                    written.add(key(x1))
-                    if x2 is not None:
-                        written.add(key(x2))
-                    for t in (cA, cP, cQ, work):
-                        pool.put(t)
+                    gn_backward(pre, node["pre_silu"], x1, x2, dact)
                 else:   # upsample: sum the 2x2 (1x2) children
                     g1, acc1 = gradbuf(x1)
                     a = (ptr(dact), ptr(g1), dtc, x1.shape[0] * x1.shape[1], x1.shape[2], x1.shape[3], x1.shape[4],
@@ -798,7 +864,32 @@ class _Plan:
         G[key(head["y2"])] = dhead
         written.add(key(head["y2"]))
 
+        rs_hw = (1, 1) if eng.dims >= 2 else (0, 1)
         for node in reversed(self.nodes):
+            if node["k"] == "resample":
+                # y = avgpool / nearest-upsample(x): the transposed map into the gradient of x (accumulating if x has other consumers)
+                dy = G.pop(key(node["y"]), None)
+                if dy is None:
+                    raise hip.RhoHipError("internal: missing gradient of a resampled tensor in the backward plan")
+                xt = node["x"]
+                gx, accx = gradbuf(xt)
+                a = (ptr(dy), ptr(gx), dtc, xt.shape[0] * xt.shape[1], xt.shape[2], xt.shape[3], xt.shape[4], rs_hw[0], rs_hw[1], int(accx))
+                if node["mode"] == "up":
+                    emit(lambda s, a=a: L.rho_pool2x_sum(*a, s), "pool2x", nbytes=5.0 * esz * xt.numel())
+                else:
+                    emit(lambda s, a=a: L.rho_avgpool2x_bwd(*a, s), "avgpool_bwd", nbytes=3.0 * esz * xt.numel())
+                written.add(key(xt))
+                pool.put(dy)
+                continue
+            if node["k"] == "act":
+                dact = G.pop(key(node["y"]), None)
+                if dact is None:
+                    raise hip.RhoHipError("internal: missing gradient of a materialised activation in the backward plan")
+                gn_backward(node["pre"], node["pre_silu"], node["x1"], node["x2"], dact)
+                pool.put(dact)
+                pre = node["pre"]
+                self.bwd_marks.append((len(bw), [pre["norm"].weight, pre["norm"].bias]))
+                continue
             if node["k"] == "attn":
                 dao = G.get(key(node["ao"]))
                 N, T, Cc = node["N"], node["T"], node["C"]

@@ -98,8 +98,20 @@ def upsample_conv(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], d
     return y2.view(N, weight.shape[0], *spatial)
 
 
+def avg_pool(x: Tensor, kernel_size, stride) -> Tensor:
+    """layers.avg_pool_nd forward for kernel = stride = 2 (3-D: (1, 2, 2))."""
+    dims = _dims_of(x)
+    ks = tuple(kernel_size) if isinstance(kernel_size, (tuple, list)) else (kernel_size,) * dims
+    st = tuple(stride) if isinstance(stride, (tuple, list)) else (stride,) * dims
+    want = (1, 2, 2) if dims == 3 else (2,) * dims
+    if ks != want or st != want:
+        raise hip.RhoHipError(f"HIP average pooling implements kernel = stride = {want} (what Downsample builds, unet_v2.py:153,165)")
+    ycl = ops.avgpool2x(_to_cl(x), (1, 1) if dims >= 2 else (0, 1))
+    return _from_cl(ycl, dims)[:, :x.shape[1]].contiguous()
+
+
 def resblock(blk, x: Tensor, emb: Tensor) -> Tensor:
-    """models.unet_v2.ResBlock forward (unet_v2.py:273-293)."""
+    """models.unet_v2.ResBlock forward (unet_v2.py:273-293), incl. the up / down form (:277-281)."""
     from torch import nn
     dims = blk.dims
     xcl = _to_cl(x)
@@ -111,8 +123,22 @@ def resblock(blk, x: Tensor, emb: Tensor) -> Tensor:
     c_in, c_out = blk.in_layers[2], blk.out_layers[3]
     w1 = ops.prep_conv_weight(c_in.weight.detach(), _DT)
     radd = None if blk.use_scale_shift_norm else emb_out
-    t1, _ = ops.conv(xcl, None, w1, c_in.bias.detach(), kernel=_k3(c_in.weight), cout=cout, pre_a=a1, pre_b=b1,
-                     pre_silu=True, res_add=radd, res_add_stride=cout)
+    if getattr(blk, "updown", False):
+        # h = in_conv(h_upd(SiLU(GN(x)))), x = x_upd(x): the activation is materialised, both tensors resampled as passes of their own
+        from .models.unet_v2 import Upsample as _Up
+        rs = (1, 1) if dims >= 2 else (0, 1)
+        act = torch.empty_like(xcl)
+        hip.check(hip.lib().rho_gn_apply(xcl.data_ptr(), xcl.shape[-1], None, 0, hip.dtype_code(xcl.dtype), xcl.shape[0],
+                                         xcl.shape[1] * xcl.shape[2] * xcl.shape[3], a1.data_ptr(), b1.data_ptr(), 1, act.data_ptr(),
+                                         hip.stream()), "rho_gn_apply")
+        if isinstance(blk.h_upd, _Up):
+            hh, xcl = ops.upsample2x(act, rs), ops.upsample2x(xcl, rs)
+        else:
+            hh, xcl = ops.avgpool2x(act, rs), ops.avgpool2x(xcl, rs)
+        t1, _ = ops.conv(hh, None, w1, c_in.bias.detach(), kernel=_k3(c_in.weight), cout=cout, res_add=radd, res_add_stride=cout)
+    else:
+        t1, _ = ops.conv(xcl, None, w1, c_in.bias.detach(), kernel=_k3(c_in.weight), cout=cout, pre_a=a1, pre_b=b1,
+                         pre_silu=True, res_add=radd, res_add_stride=cout)
     if blk.use_scale_shift_norm:
         a2, b2, _ = ops.gn_coeffs(t1, None, n1.weight.detach(), n1.bias.detach(), scale=emb_out, shift=emb_out[:, cout:],
                                   film_stride=2 * cout)

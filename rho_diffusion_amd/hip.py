@@ -94,6 +94,8 @@ SIGNATURES = {
     "rho_chan_sum": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p]),
     "rho_upsample2x": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
     "rho_pool2x_sum": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "rho_avgpool2x": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "rho_avgpool2x_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
     "rho_linear_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int,
                                c_int, c_int, c_void_p]),
     "rho_add_inplace": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),

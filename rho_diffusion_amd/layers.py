@@ -51,15 +51,35 @@ def conv_nd(dims, *args, **kwargs):
     raise ValueError(f"unsupported dimensions: {dims}")
 
 
+class _HipAvgPoolMixin:
+    """kernel = stride = 2 (3-D: (1, 2, 2)): the only pooling the UNet builds (unet_v2.py:153,165); runs rho_avgpool2x."""
+
+    def forward(self, x):
+        from . import functional as HF
+        return HF.avg_pool(x, self.kernel_size, self.stride)
+
+
+class HipAvgPool1d(_HipAvgPoolMixin, nn.AvgPool1d):
+    pass
+
+
+class HipAvgPool2d(_HipAvgPoolMixin, nn.AvgPool2d):
+    pass
+
+
+class HipAvgPool3d(_HipAvgPoolMixin, nn.AvgPool3d):
+    pass
+
+
 @registry.register_layer("avg_pool_nd")
 def avg_pool_nd(dims, *args, **kwargs):
-    """layers.py:91-102.  Not reached by any shipped configuration (conv_resample=True)."""
+    """1-D / 2-D / 3-D average pooling module (layers.py:91-102); ValueError for other dims."""
     if dims == 1:
-        return nn.AvgPool1d(*args, **kwargs)
+        return HipAvgPool1d(*args, **kwargs)
     elif dims == 2:
-        return nn.AvgPool2d(*args, **kwargs)
+        return HipAvgPool2d(*args, **kwargs)
     elif dims == 3:
-        return nn.AvgPool3d(*args, **kwargs)
+        return HipAvgPool3d(*args, **kwargs)
     raise ValueError(f"unsupported dimensions: {dims}")
 
 

@@ -77,15 +77,13 @@ class Downsample(nn.Module):
 
 class ResBlock(TimestepBlock):
     """GN-SiLU-conv, FiLM (scale-shift) or additive embedding, GN-SiLU-conv(zero-init), skip
-    (unet_v2.py:172-293).  ``up`` / ``down`` (resblock_updown) are not supported: no shipped
-    configuration uses them."""
+    (unet_v2.py:172-293).  ``up`` / ``down`` (resblock_updown): the activated input and the skip input are resampled
+    (nearest x2 / average pool) before the first conv (:277-281)."""
 
     def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False,
                  use_scale_shift_norm=False, dims=2, use_checkpoint=False, up=False, down=False,
                  activation=nn.SiLU()):
         super().__init__()
-        if up or down:
-            raise NotImplementedError("resblock_updown is not supported by the HIP engine")
         if dropout:
             raise NotImplementedError("dropout > 0 is not supported by the HIP engine (all shipped configs use 0)")
         if not isinstance(activation, nn.SiLU):
@@ -101,8 +99,15 @@ class ResBlock(TimestepBlock):
 
         self.in_layers = nn.Sequential(normalization(channels), activation,
                                        conv_nd(dims, channels, self.out_channels, 3, padding=1))
-        self.updown = False
-        self.h_upd = self.x_upd = nn.Identity()
+        self.updown = up or down
+        if up:
+            self.h_upd = Upsample(channels, False, dims)
+            self.x_upd = Upsample(channels, False, dims)
+        elif down:
+            self.h_upd = Downsample(channels, False, dims)
+            self.x_upd = Downsample(channels, False, dims)
+        else:
+            self.h_upd = self.x_upd = nn.Identity()
         self.emb_layers = nn.Sequential(
             activation,
             nn.Linear(emb_channels, 2 * self.out_channels if use_scale_shift_norm else self.out_channels))
@@ -160,8 +165,6 @@ class UNet(nn.Module):
         super().__init__()
         if num_heads_upsample == -1:
             num_heads_upsample = num_heads
-        if resblock_updown or not conv_resample:
-            raise NotImplementedError("HIP engine supports conv_resample=True, resblock_updown=False (all shipped configs)")
 
         self.data_shape = data_shape
         self.in_channels = in_channels
@@ -193,9 +196,11 @@ class UNet(nn.Module):
         if self.num_classes is not None:
             self.label_emb = None
 
-        def res(cin, cout):
+        self.resblock_updown = resblock_updown
+
+        def res(cin, cout, **updown):
             return ResBlock(cin, embedding_dim, dropout, out_channels=cout, dims=dims, use_checkpoint=use_checkpoint,
-                            use_scale_shift_norm=use_scale_shift_norm, activation=activation)
+                            use_scale_shift_norm=use_scale_shift_norm, activation=activation, **updown)
 
         def attn(c, heads):
             return AttentionBlock(c, use_checkpoint=use_checkpoint, num_heads=heads, num_head_channels=num_head_channels,
@@ -216,7 +221,8 @@ class UNet(nn.Module):
                 self._feature_size += ch
                 input_block_chans.append(ch)
             if level != len(channel_mult) - 1:
-                self.input_blocks.append(TimestepEmbedSequential(Downsample(ch, conv_resample, dims=dims, out_channels=ch)))
+                self.input_blocks.append(TimestepEmbedSequential(
+                    res(ch, ch, down=True) if resblock_updown else Downsample(ch, conv_resample, dims=dims, out_channels=ch)))
                 input_block_chans.append(ch)
                 ds *= 2
                 self._feature_size += ch
@@ -233,7 +239,7 @@ class UNet(nn.Module):
                 if ds in attention_resolutions:
                     layers.append(attn(ch, num_heads_upsample))
                 if level and i == num_res_blocks:
-                    layers.append(Upsample(ch, conv_resample, dims=dims, out_channels=ch))
+                    layers.append(res(ch, ch, up=True) if resblock_updown else Upsample(ch, conv_resample, dims=dims, out_channels=ch))
                     ds //= 2
                 self.output_blocks.append(TimestepEmbedSequential(*layers))
                 self._feature_size += ch

@@ -45,3 +45,15 @@ WIDE_CASES = {
 def galaxy_labels(B):
     keys = list(DEEP_GALAXY_SPACE.keys())
     return [[float(DEEP_GALAXY_SPACE[k][(3 * i + 5 * j + 1) % len(DEEP_GALAXY_SPACE[k])]) for j, k in enumerate(keys)] for i in range(B)]
+
+
+# ---- K12: ResBlock(up / down) and conv-less (average pool / nearest) resampling (unet_v2.py:165,221-224,277-281); g15_updown.npz
+UPDOWN_CASES = {
+    "updown2d": (dict(_tiny, dims=2, data_shape=[16, 16], resblock_updown=True), (2, 1, 16, 16), None),
+    "updown3d_add": (dict(_tiny, dims=3, data_shape=[4, 8, 8], resblock_updown=True, use_scale_shift_norm=False), (2, 1, 4, 8, 8), None),
+    "avgpool3d": (dict(_tiny, dims=3, data_shape=[4, 8, 8], conv_resample=False), (2, 1, 4, 8, 8), None),
+    "avgpool1d": (dict(_tiny, dims=1, data_shape=[32], conv_resample=False), (2, 1, 32), None),
+    "updown2d_3lvl": (dict(in_channels=1, out_channels=1, model_channels=32, num_res_blocks=1, channel_mult=(1, 2, 2), attention_resolutions=[4],
+                           num_heads=2, use_scale_shift_norm=True, dims=2, data_shape=[16, 24], resblock_updown=True, conv_resample=False),
+                      (2, 1, 16, 24), None),
+}

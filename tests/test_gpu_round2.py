@@ -9,8 +9,8 @@ import pytest
 import torch
 from torch import nn
 
-from helpers import (DEEP_GALAXY_SPACE, PARAM_SPACE, UNET_CASES, case_inputs, det_normal, det_state_dict, det_uniform, galaxy_labels,
-                     golden_template, load_golden, rel_l2)
+from helpers import (DEEP_GALAXY_SPACE, PARAM_SPACE, UNET_CASES, UPDOWN_CASES, case_inputs, cosine, det_normal, det_state_dict, det_uniform,
+                     galaxy_labels, golden_template, grad_digest_of, load_golden, rel_l2)
 from gpu_util import DEV
 from oracle import ref_torch as R
 
@@ -412,3 +412,83 @@ def test_script_shaped_flow_config_registry_train_checkpoint_sample(tmp_path, mo
     t = torch.tensor([3, 17], device="cuda")
     with torch.no_grad():
         assert torch.equal(fresh.backbone(x, t, y), ddpm.backbone(x, t, y))
+
+
+# ----------------------------------------------------------------------------- K12: avg_pool_nd / resblock_updown
+def test_avgpool_kernels_vs_oracle(ops):
+    """rho_avgpool2x / rho_avgpool2x_bwd against torch's avg_pool and its autograd, odd extents included (floor), bf16 and fp32."""
+    import torch.nn.functional as F
+    from gpu_util import from_cl, rnd, to_cl
+    for dims, shape in [(2, (2, 32, 7, 9)), (3, (1, 32, 3, 6, 5)), (1, (2, 64, 11)), (3, (2, 64, 4, 8, 8))]:
+        for dtype in (torch.float32, torch.bfloat16):
+            x = rnd(det_normal(shape, "apx"), dtype).requires_grad_(True)
+            y = R.avg_pool(dims, x)
+            dy = rnd(det_normal(tuple(y.shape), "apdy"), dtype)
+            y.backward(dy)
+            hw = (1, 1) if dims >= 2 else (0, 1)
+            xcl = to_cl(x.detach(), dtype)
+            ycl = ops.avgpool2x(xcl, hw)
+            assert rel_l2(from_cl(ycl, dims), y.detach()) < (1e-6 if dtype == torch.float32 else 4e-3)
+            base = rnd(det_normal(shape, "apbase"), dtype)
+            dx = to_cl(base, dtype)
+            ops.avgpool2x_bwd(to_cl(dy, dtype), dx, hw, accumulate=True)
+            assert rel_l2(from_cl(dx, dims) - base, x.grad) < (1e-6 if dtype == torch.float32 else 8e-3)
+            dx2 = torch.full_like(dx, 7.0)
+            ops.avgpool2x_bwd(to_cl(dy, dtype), dx2, hw, accumulate=False)
+            assert rel_l2(from_cl(dx2, dims), x.grad) < (1e-6 if dtype == torch.float32 else 4e-3)
+
+
+def test_updown_modules_vs_reference_golden():
+    """Stand-alone ResBlock(up / down), Downsample / Upsample without conv (golden g15)."""
+    from rho_diffusion_amd.models import Downsample, ResBlock, Upsample
+    g = load_golden("g15_updown.npz")
+    with torch.no_grad():
+        for name, dims, c, cout, shape, kind in [("resup2d", 2, 32, 64, (2, 32, 6, 8), "up"), ("resdown2d", 2, 32, 32, (2, 32, 8, 12), "down"),
+                                                 ("resup3d", 3, 32, 32, (1, 32, 3, 4, 6), "up"), ("resdown3d", 3, 64, 32, (2, 64, 4, 6, 8), "down"),
+                                                 ("resdown1d", 1, 32, 32, (2, 32, 20), "down")]:
+            blk = ResBlock(c, 128, 0.0, out_channels=cout, dims=dims, use_scale_shift_norm=True, up=(kind == "up"), down=(kind == "down"))
+            blk.load_state_dict(det_state_dict(blk.state_dict(), name))
+            y = blk.to(DEV)(det_normal(shape, name + "x").to(DEV), det_normal((shape[0], 128), name + "emb").to(DEV))
+            assert rel_l2(y, torch.from_numpy(g[f"{name}/y"])) < 5e-5, name
+        for name, dims, shape in [("pool2d_odd", 2, (2, 32, 7, 9)), ("pool3d", 3, (1, 32, 3, 6, 5)), ("pool1d", 1, (2, 32, 11))]:
+            x = det_normal(shape, name + "x").to(DEV)
+            assert rel_l2(Downsample(32, False, dims=dims).to(DEV)(x), torch.from_numpy(g[f"{name}/y"])) < 1e-6, name
+            assert rel_l2(Upsample(32, False, dims=dims).to(DEV)(x), torch.from_numpy(g[f"{name}/up"])) < 1e-6, name
+
+
+@pytest.mark.parametrize("case", list(UPDOWN_CASES.keys()))
+def test_updown_unets_forward_and_gradients_vs_reference_golden(case):
+    """resblock_updown = True / conv_resample = False UNets: state_dict layout, fp32 forward 1e-4 + gradient norms 2e-3, bf16 forward
+    3e-2 + per-parameter gradient cosine >= 0.99 against the oracle (pinned to the reference by g15)."""
+    from rho_diffusion_amd.autograd import mse_loss
+    from rho_diffusion_amd.models import UNet
+    g = load_golden("g15_updown.npz")
+    kw, xshape, _ = UPDOWN_CASES[case]
+    sd = det_state_dict(golden_template(g, case), case)
+    x = det_normal(xshape, case + "x")
+    t = torch.tensor([(37 * i + 11) % 1000 for i in range(xshape[0])])
+    gold = torch.from_numpy(g[f"{case}/pred"])
+    target = det_normal(tuple(gold.shape), case + "tgt")
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    torch.nn.functional.mse_loss(R.unet_forward(sdg, dict(kw), x, t), target).backward()
+    gtot = math.sqrt(sum(float(v.grad.double().norm()) ** 2 for v in sdg.values() if v.grad is not None))
+    for dtype in ("fp32", "bf16"):
+        model = UNet(**dict(kw, compute_dtype=dtype))
+        assert [f"{k}|{','.join(map(str, v.shape))}" for k, v in model.state_dict().items()] == [str(s_) for s_ in g[f"{case}/keys"]]
+        model.load_state_dict(sd)
+        model = model.to(DEV).train()
+        pred = model(x.to(DEV), t.to(DEV))
+        assert rel_l2(pred, gold) < (1e-4 if dtype == "fp32" else 3e-2), (case, dtype, rel_l2(pred, gold))
+        loss = mse_loss(pred, target.to(DEV))
+        loss.backward()
+        bad = []
+        for name, p in model.named_parameters():
+            ref = g[f"{case}/grad/{name}"]
+            if dtype == "fp32":
+                if abs(grad_digest_of(p.grad)[0] - ref[0]) > 2e-3 * ref[0] + 1e-6:
+                    bad.append((name, grad_digest_of(p.grad)[0], ref[0]))
+            elif ref[0] >= 1e-5 * gtot:
+                c = cosine(p.grad, sdg[name].grad)
+                if c < 0.99 or abs(float(p.grad.double().norm()) - ref[0]) > 0.05 * ref[0]:
+                    bad.append((name, round(c, 4), float(p.grad.double().norm()) / ref[0]))
+        assert not bad, (dtype, bad[:6])

@@ -5,7 +5,7 @@ import pytest
 import torch
 from pytest import approx
 
-from helpers import (PARAM_SPACE, UNET_CASES, WIDE_CASES, case_inputs, det_normal, det_state_dict, det_uniform,
+from helpers import (PARAM_SPACE, UNET_CASES, UPDOWN_CASES, WIDE_CASES, case_inputs, det_normal, det_state_dict, det_uniform,
                      golden_template, grad_digest_of, load_golden, rel_l2, wide_case_inputs)
 from oracle import ref_torch as R
 
@@ -228,6 +228,53 @@ def test_g14_spherical_harmonic_fields():
             np.testing.assert_allclose(mom, g[key], rtol=1e-6)
         seen += 1
     assert seen >= 24 + 12
+
+
+@pytest.mark.parametrize("case", list(UPDOWN_CASES.keys()))
+def test_g15_updown_and_pooled_unets(case):
+    """K12: resblock_updown = True and conv_resample = False networks (unet_v2.py:165,221-224,277-281)."""
+    g = load_golden("g15_updown.npz")
+    kw, xshape, _ = UPDOWN_CASES[case]
+    cfg = dict(kw)
+    x = det_normal(xshape, case + "x")
+    t = torch.tensor([(37 * i + 11) % 1000 for i in range(xshape[0])])
+    sd = {k: v.requires_grad_(True) for k, v in det_state_dict(golden_template(g, case), case).items()}
+    pred = R.unet_forward(sd, cfg, x, t)
+    assert rel_l2(pred, torch.from_numpy(g[f"{case}/pred"])) < TOL
+    loss = torch.nn.functional.mse_loss(pred, det_normal(tuple(pred.shape), case + "tgt"))
+    assert abs(loss.item() - float(g[f"{case}/loss"])) < 1e-5
+    loss.backward()
+    n = 0
+    for k, v in sd.items():
+        if f"{case}/grad/{k}" in g.files and v.grad is not None:
+            ref = g[f"{case}/grad/{k}"]
+            assert abs(grad_digest_of(v.grad)[0] - ref[0]) <= 1e-4 * ref[0] + 1e-6, k
+            n += 1
+    assert n > 20
+
+
+def test_g15_updown_modules():
+    g = load_golden("g15_updown.npz")
+    E = 128
+    for name, dims, c, cout, shape, kind in [("resup2d", 2, 32, 64, (2, 32, 6, 8), "up"), ("resdown2d", 2, 32, 32, (2, 32, 8, 12), "down"),
+                                             ("resup3d", 3, 32, 32, (1, 32, 3, 4, 6), "up"), ("resdown3d", 3, 64, 32, (2, 64, 4, 6, 8), "down"),
+                                             ("resdown1d", 1, 32, 32, (2, 32, 20), "down")]:
+        k = (3,) * dims
+        tmpl = {"in_layers.0.weight": torch.empty(c), "in_layers.0.bias": torch.empty(c),
+                "in_layers.2.weight": torch.empty(cout, c, *k), "in_layers.2.bias": torch.empty(cout),
+                "emb_layers.1.weight": torch.empty(2 * cout, E), "emb_layers.1.bias": torch.empty(2 * cout),
+                "out_layers.0.weight": torch.empty(cout), "out_layers.0.bias": torch.empty(cout),
+                "out_layers.3.weight": torch.empty(cout, cout, *k), "out_layers.3.bias": torch.empty(cout)}
+        if c != cout:
+            tmpl["skip_connection.weight"] = torch.empty(cout, c, *((1,) * dims))
+            tmpl["skip_connection.bias"] = torch.empty(cout)
+        sd = det_state_dict(tmpl, name)
+        y = R.resblock(dims, det_normal(shape, name + "x"), det_normal((shape[0], E), name + "emb"), sd, "", True, updown=kind)
+        assert rel_l2(y, torch.from_numpy(g[f"{name}/y"])) < TOL, name
+    for name, dims, shape in [("pool2d_odd", 2, (2, 32, 7, 9)), ("pool3d", 3, (1, 32, 3, 6, 5)), ("pool1d", 1, (2, 32, 11))]:
+        x = det_normal(shape, name + "x")
+        assert torch.equal(R.avg_pool(dims, x), torch.from_numpy(g[f"{name}/y"])), name
+        assert torch.equal(R.upsample(dims, x), torch.from_numpy(g[f"{name}/up"])), name
 
 
 GD_TABLES = ("betas", "alphas_cumprod", "alphas_cumprod_prev", "alphas_cumprod_next", "sqrt_alphas_cumprod",
