@@ -187,19 +187,18 @@ def roofline_of(plan, args):
     traffic = mfma_util = None
     traffic_note = "no PMC summary under profiles/ for this binary"
     import glob
-    for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_conv3.json")), reverse=True):
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_conv3.json")))[-1:]      # names carry the round: r02b > r02a > r01h
+    for tpath in newest:
         with open(tpath) as f:
             tj = json.load(f)
         if tj.get("build_id") != build:
             traffic_note = (f"{os.path.relpath(tpath, ROOT)} was measured on build {tj.get('build_id', '(unrecorded)')}, this is {build}: "
                             "not reported (re-run tests/gpu_pmc.sh)")
-            continue
-        if tj.get("workload") != dict(dims=args.dims, grid=args.grid, mc=args.mc, batch=args.batch, dtype=args.dtype, labels=args.labels):
+        elif tj.get("workload") != dict(dims=args.dims, grid=args.grid, mc=args.mc, batch=args.batch, dtype=args.dtype, labels=args.labels):
             traffic_note = f"{os.path.relpath(tpath, ROOT)} covers another workload"
-            continue
-        traffic, mfma_util = tj["hbm_bytes_per_launch"], tj.get("mfma_util")
-        traffic_note = f"{os.path.relpath(tpath, ROOT)} (build {build}; PMC FETCH_SIZE x2 + WRITE_SIZE, average per launch of the same conv3 launches)"
-        break
+        else:
+            traffic, mfma_util = tj["hbm_bytes_per_launch"], tj.get("mfma_util")
+            traffic_note = f"{os.path.relpath(tpath, ROOT)} (build {build}; PMC FETCH_SIZE x2 + WRITE_SIZE, average per launch of the same conv3 launches)"
     alg_bytes = sum(p["bytes"] for p in conv3)
     return {
         "bound": "mfma", "kernel": "k_conv (3x3x3 implicit GEMM, LDS halo tile)", "achieved": achieved, "peak": peak,
