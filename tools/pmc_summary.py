@@ -41,6 +41,23 @@ def durations():
     return dur
 
 
+def clocks():
+    """kernel name -> effective shader clock in GHz over the GRBM pass: sum(GRBM_GUI_ACTIVE) / 8 XCDs / sum(kernel duration of the
+    same pass) (MI355X_MICROARCH.md, DVFS give-back: within 3 % of the in-kernel clock on dispatches of >= 0.3 ms)."""
+    act, dur = collections.defaultdict(float), collections.defaultdict(float)
+    base = os.path.join(ROOT, "gpurun_out", PMC_DIR, "grbm")
+    cfiles = sorted(glob.glob(os.path.join(base, "**/*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]
+    tfiles = sorted(glob.glob(os.path.join(base, "**/*kernel_trace.csv"), recursive=True), key=os.path.getmtime)[-1:]
+    for f in cfiles:
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                act[r["Kernel_Name"]] += float(r["Counter_Value"])
+    for f in tfiles:
+        for r in csv.DictReader(open(f)):
+            dur[r["Kernel_Name"]] += (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-9
+    return {k: act[k] / 8.0 / dur[k] / 1e9 for k in act if dur.get(k)}
+
+
 sq = collections.defaultdict(dict)
 for sub in ("sq1", "sq2", "fetch", "write"):
     agg, calls = collect(sub)
@@ -57,6 +74,10 @@ for k, v in sq.items():
         v["WAIT_INST_ANY_frac"] = v.get("SQ_WAIT_INST_ANY", 0) / v["SQ_WAVE_CYCLES"]
         v["WAIT_ANY_frac"] = v.get("SQ_WAIT_ANY", 0) / v["SQ_WAVE_CYCLES"]
     out[k[:110]] = v
+CLK = clocks()
+for k, v in sq.items():
+    if k in CLK:
+        v["effective_clock_GHz"] = CLK[k]
 # MFMA utilisation against the gfx950 peak issue rate: wave-level MFMA instructions x SIMD cycles each (32 for 32x32x16 bf16,
 # 16 for 16x16x32 bf16, 64 for 32x32x2 f32: MI355X_MICROARCH.md cycle constants) / (1024 SIMDs x kernel time x 2.4 GHz)
 DUR = durations()
@@ -80,6 +101,7 @@ mf = sum(sq[k].get("SQ_INSTS_MFMA", 0.0) * sq[k].get("mfma_cycles_per_inst_assum
 dsum = sum(DUR.get(k, 0.0) for k in conv3)
 tj = {"kernel": "k_conv<bf16,3,3,3,*> (all variants)", "build_id": meta.get("build_id"), "workload": meta.get("workload"),
       "mfma_util": (mf / (1024.0 * dsum * 2.4e9)) if dsum > 0 else None,
+      "effective_clock_GHz": ({k[:60]: round(CLK[k], 3) for k in conv3 if k in CLK} or None),
       "mfma_util_note": "sum over the conv3 variants of SQ_INSTS_MFMA x SIMD cycles per instruction / (1024 SIMDs x summed kernel time "
                         "of the un-instrumented trace pass x 2.4 GHz)",
       "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --mode sample --steps 2 "
