@@ -24,6 +24,10 @@
 
 #include "conv_common.h"
 
+// Taps per workgroup barrier of the 8-wave M16 variant (with the tap order pinned, see RHO_FENCE: 3 is 3 % faster than 1; the
+// LDS weight ring is 9 slots deep then).  The host sizes the ring with the same constant.
+#define RHO_GB_WIDE 3
+
 struct ConvK {
     const char* x1;
     const char* x2;
@@ -223,7 +227,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
     // weight tile: BM rows x 4 pieces of 16 B; thread -> row (tid>>2) + 64*k, piece tid&3.
     // (plain scalars, no arrays by reference: those end up in scratch)
     const bool w_active = (BM >= RPP) || (tid < BM * 4);
-    const char* const w_src0 = p.w + ((size_t)co0 + (tid >> 2)) * wrow_bytes + piece * 16;
+    // address = uniform 64-bit base (tap, chunk, cout tile: scalar ALU) + one 32-bit per-thread offset, the `saddr` form of
+    // global_load: per-tap 64-bit pointers in VGPRs (27 taps x 2 registers, hoisted out of the chunk loop) spilled to scratch
+    const char* const w_src0 = p.w + (size_t)co0 * wrow_bytes;
+    // (re-declared opaque at every chunk: otherwise base + tap * stride + offset is hoisted as 27 per-lane 64-bit pointers anyway)
+    unsigned w_voff = (unsigned)(tid >> 2) * (unsigned)wrow_bytes + (unsigned)piece * 16u;         // < 128 rows x 16 KiB
     const size_t w_tap_stride = (size_t)p.coutp * wrow_bytes;
     int w_row = tid >> 2;                  // LDS row of this thread's weight row(s); rows RPP apart keep the permutation
     if constexpr (M16) w_row = (w_row & ~31) + 16 * m16_hb(w_row & 15) + 2 * m16_k8(w_row & 15) + ((w_row >> 4) & 1);
@@ -244,9 +252,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
     do {                                                                                                \
         _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_) {                                              \
             const char* ws_ = w_src0 + (size_t)((st_) * G + g_) * w_tap_stride + (size_t)(ck_) * 64;    \
-            if (w_active) wq0[set_][g_] = *reinterpret_cast<const uint4*>(ws_);                         \
-            if constexpr (WROWS == 2) wq1[set_][g_] = *reinterpret_cast<const uint4*>(ws_ + RPP * wrow_bytes); \
+            if (w_active) wq0[set_][g_] = *reinterpret_cast<const uint4*>(ws_ + w_voff);                \
+            if constexpr (WROWS == 2) wq1[set_][g_] = *reinterpret_cast<const uint4*>(ws_ + RPP * wrow_bytes + w_voff); \
         }                                                                                               \
+    } while (0)
+// PIPE paths inside the chunk loop: the fetch pointer `wl` walks tap by tap (a loop-carried scalar: nothing to hoist, two scalar
+// adds per tap; 27 hoisted 64-bit bases overflowed the SGPR file and came back as v_readlane per use).
+#define RHO_LOAD_WP(set_, st_)                                                                          \
+    do {                                                                                                \
+        if (w_active) wq0[set_][0] = *reinterpret_cast<const uint4*>(wl + w_voff);                      \
+        if constexpr (WROWS == 2) wq1[set_][0] = *reinterpret_cast<const uint4*>(wl + RPP * wrow_bytes + w_voff); \
+        if (((st_) + LD) % NS == NS - 1) wl = w_src0 + (size_t)min(ck + ((st_) + LD) / NS + 1, nck - 1) * 64; \
+        else wl += w_tap_stride;                                                                        \
     } while (0)
 #define RHO_STORE_W(buf_, set_)                                                                         \
     do {                                                                                                \
@@ -266,7 +283,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
     constexpr bool PIPE = (NS % 3 == 0) && (G == 1);
     // measured on the 8-wave 128-cout variant: GB = 3, R = 9 is 3 % SLOWER than a barrier per tap (131 vs 127 ms per
     // c3 step) - the per-tap barrier is not what limits this kernel - so GB stays 1.
-    constexpr int GB = 1;
+    // (the slot of a step is st % RS: the ring depth must divide the taps of a chunk - 9 | 27 and 9 | 9, not the 3 taps of 1-D)
+    constexpr int GB = (BM == 128 && NW == 8 && M16 && NS % 9 == 0) ? RHO_GB_WIDE : 1;
     constexpr int RS = (GB == 3) ? 9 : 3;          // LDS ring slots
     constexpr int DS = GB + 1;                     // store distance
     constexpr int LD = DS + 2;                     // load distance
@@ -284,6 +302,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
             __syncthreads();
         }
     }
+    const char* wl = w_src0;
     if constexpr (NT != 1) {
     if constexpr (PIPE) {
         RHO_LOAD_W(0, 0, 0);
@@ -296,6 +315,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
         for (int q = 3; q < LD; ++q) RHO_LOAD_W(q % 3, min(q / NS, nck - 1), q % NS);
 #pragma unroll
         for (int q = 3; q < DS; ++q) RHO_STORE_W(q % RS, q % 3);
+        wl = w_src0 + (size_t)(LD % NS) * w_tap_stride + (size_t)min(LD / NS, nck - 1) * 64;   // step LD: fetched at tap 0 of chunk 0
     } else {
         // steps 0 .. PD-1 of chunk 0 in flight (PD <= NS), step 0 landed in LDS slot 0
 #pragma unroll
@@ -329,6 +349,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
     if constexpr (HPF) RHO_HALO_LOAD(0);
 
     for (int ck = 0; ck < nck; ++ck) {
+        if constexpr (M16) asm volatile("" : "+v"(w_voff));
         // ---- stage the halo tile of this channel chunk (previous chunk's reads are fenced by the
         //      barrier that closed its last tap)
         {
@@ -400,19 +421,27 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
             //   phase 0 reads a23 (phase 2) | 1 reads the next tap's F | 2 reads the next tap's a01 | 3 reads the next tap's S.
             static_assert(MT == 2 && NS % 2 == 1, "M16 tap schedule: 64 couts per wave, odd tap count");
             typedef float f32x4_t __attribute__((ext_vector_type(4)));
-            uint4 a01[2], a23[2], bS[2], bF[2][2];
-            auto rdA = [&](int slot, int tp, uint4 (&fa)[2]) {
+            typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+            u32x4_t a01[2], a23[2], bS[2][2], bF[2][2];
+            auto rdA = [&](int slot, int tp, u32x4_t (&fa)[2]) {
                 const char* w = wbuf + (size_t)slot * SLOT + a_off + tp * 32 * PITCH;
-                fa[0] = *reinterpret_cast<const uint4*>(w);
-                fa[1] = *reinterpret_cast<const uint4*>(w + PITCH);
+                fa[0] = *reinterpret_cast<const u32x4_t*>(w);
+                fa[1] = *reinterpret_cast<const u32x4_t*>(w + PITCH);
             };
-            auto rdB = [&](int tap, int jp, uint4 (&fb)[2]) {
+            // stride 1, no upsampling (M16): a tap shifts every lane by the same (kd * IH * IW + kh * IW + kw) rows - a scalar
+            // added to one per-lane base per column pair, instead of 27 x 2 per-lane offsets kept in VGPRs across the chunk loop
+            const int bbase[2] = {offd[0] + offh[0][0] + offw[0][0], offd[1] + offh[1][0] + offw[1][0]};
+            // (opaque per chunk: computed by the scalar ALU at each use - hoisted out of the chunk loop the 27 offsets and the 27
+            //  weight bases overflow the SGPR file and come back as v_readlane per use)
+            int ihs = p.IH, iws = p.IW;
+            asm volatile("" : "+s"(ihs), "+s"(iws));
+            auto rdB = [&](int tap, int jp, u32x4_t (&fb)[2]) {
                 const int kd = tap / (KH * KW), kh = (tap / KW) % KH, kw = tap % KW;
-                const char* b = halo + (kd * p.IH * p.IW * PITCH + offd[jp] + offh[jp][kh] + offw[jp][kw]);
-                fb[0] = *reinterpret_cast<const uint4*>(b);
-                fb[1] = *reinterpret_cast<const uint4*>(b + PITCH);
+                const char* b = halo + (bbase[jp] + ((kd * ihs + kh) * iws + kw) * PITCH);
+                fb[0] = *reinterpret_cast<const u32x4_t*>(b);
+                fb[1] = *reinterpret_cast<const u32x4_t*>(b + PITCH);
             };
-            auto mm = [&](const uint4 (&fa)[2], const uint4 (&fb)[2], int tp, int jp) {   // tp, jp: compile-time after unrolling
+            auto mm = [&](const u32x4_t (&fa)[2], const u32x4_t (&fb)[2], int tp, int jp) {   // tp, jp: compile-time after unrolling
                 f32x16_t& c = acc[tp][jp];
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt)
@@ -427,14 +456,20 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
             };
             rdA(0, 0, a01);
             rdB(0, 0, bF[0]);
-            rdB(0, 1, bS);
+            rdB(0, 1, bS[0]);
+            // MFMA intrinsics carry no chain: instruction selection gathers a tap's 16 MFMAs and the scheduler then bursts the
+            // fragment reads right before the barrier's lgkmcnt(0).  An empty volatile asm that passes the fragments a group is
+            // about to use pins the order: the group's MFMAs come after it (data), the reads issued before it stay before it
+            // (memory clobber) - so every read is issued two groups (>= 128 MFMA cycles) ahead of its first use.
+#define RHO_PHASE() __builtin_amdgcn_sched_barrier(0)
+#define RHO_FENCE(A_, B_)                                                                                             \
+    do {                                                                                                              \
+        asm volatile("" : "+v"(A_[0]), "+v"(A_[1]), "+v"(B_[0]), "+v"(B_[1]) : : "memory");                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+    } while (0)
 #pragma unroll
             for (int st = 0; st < NS; ++st) {
-                {
-                    const int nst = (st + LD) % NS;
-                    const int nckk = min(ck + (st + LD) / NS, nck - 1);
-                    RHO_LOAD_W((st + LD) % 3, nckk, nst);
-                }
+                RHO_LOAD_WP((st + LD) % 3, st);
                 if constexpr (HPF) {
                     if (st == TPF) {
                         __builtin_amdgcn_sched_barrier(0);     // keep the halo loads younger than the weight fetch above
@@ -445,16 +480,26 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                 const int slot = st % RS, nslot = (st + 1) % RS;
                 const bool more = st + 1 < NS;                 // next chunk's first tap: after its halo is staged
                 const int jf = st & 1, js = jf ^ 1;            // column-tile pair of F / S in this tap (swapped in the next)
+                const int fc = st & 1, fn = fc ^ 1;            // fragment buffers of this / the next tap
+                // group 0: this tap's second cout pair
                 rdA(slot, 1, a23);
-                mm(a01, bF[st & 1], 0, jf);
-                if (more) rdB(st + 1, js, bF[(st + 1) & 1]);
-                mm(a01, bS, 0, js);
+                RHO_FENCE(a01, bF[fc]);
+                mm(a01, bF[fc], 0, jf);
+                // group 1
+                if (more) rdB(st + 1, js, bF[fn]);
+                RHO_FENCE(a01, bS[fc]);
+                mm(a01, bS[fc], 0, js);
+                // group 2: the last fragment reads of the tap, two groups (>= 128 MFMA cycles) before a barrier's lgkmcnt(0)
                 if (more) rdA(nslot, 0, a01);
-                mm(a23, bS, 1, js);
-                if (more) rdB(st + 1, jf, bS);
-                mm(a23, bF[st & 1], 1, jf);
+                if (more) rdB(st + 1, jf, bS[fn]);
+                RHO_FENCE(a23, bS[fc]);
+                mm(a23, bS[fc], 1, js);
+                // group 3: the LDS weight store (fetched two taps ago; late in the tap its vmcnt wait is free)
                 RHO_STORE_W((st + DS) % RS, (st + DS) % 3);
+                RHO_FENCE(a23, bF[fc]);
+                mm(a23, bF[fc], 1, jf);
                 if (st % GB == GB - 1) __syncthreads();
+                RHO_PHASE();
             }
         } else if constexpr (PIPE) {
             // fragments: X = k-half 0 of the current step (already in flight), Y = k-half 1
@@ -575,8 +620,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                 xq[S_][i] = *reinterpret_cast<const uint4*>(src + ((size_t)ps * cs + csrc) * sizeof(T) + piece * 16);
             }
             const char* ws = w_src0 + (size_t)cc * 64;
-            if (w_active) wx0[S_] = *reinterpret_cast<const uint4*>(ws);
-            if constexpr (WROWS == 2) wx1[S_] = *reinterpret_cast<const uint4*>(ws + RPP * wrow_bytes);
+            if (w_active) wx0[S_] = *reinterpret_cast<const uint4*>(ws + w_voff);
+            if constexpr (WROWS == 2) wx1[S_] = *reinterpret_cast<const uint4*>(ws + RPP * wrow_bytes + w_voff);
         };
         // The folded GroupNorm affine of the prologue: fetched from global memory inside the chunk loop it would be the
         // youngest load in flight at every hand-over, and waiting for it (vmcnt is in-order) drains the whole register
@@ -699,7 +744,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
 #undef RHO_ONE_STEP
 #undef RHO_ONE_TAIL
     }
+#undef RHO_PHASE
+#undef RHO_FENCE
 #undef RHO_LOAD_W
+#undef RHO_LOAD_WP
 #undef RHO_STORE_W
 #undef RHO_HALO_LOAD
     // ---- epilogue: lane holds, for position column (lane&31) of tile j, channels
@@ -1064,7 +1112,8 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
 
     const size_t lds_cap = 160 * 1024;
     const int taps = d.kd * d.kh * d.kw;
-    const int WSLOTS = (taps % 3 == 0) ? 3 : 2;                 // LDS weight-ring depth (matches the kernel's PIPE / RS)
+    const bool m16 = d.dtype == RHO_BF16 && taps > 1 && d.sh == 1 && d.sw == 1 && !d.up_h && !d.up_w;
+    const int WSLOTS = (taps % 3 == 0) ? ((BM == 128 && RHO_GB_WIDE == 3 && m16 && taps % 9 == 0) ? 9 : 3) : 2;   // LDS weight-ring depth (matches the kernel's PIPE / RS)
     int np_cap = (int)((lds_cap - (size_t)WSLOTS * BM * PITCH) / PITCH);
     if (np_cap > 28 * 64) np_cap = 28 * 64;
     // prefer the small-halo (2 blocks / CU) configuration when it exists
@@ -1127,8 +1176,7 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
     if (d.split > 0 && lds < lds_epi) lds = lds_epi;
     hipStream_t st = as_stream(stream);
     static const bool m16_env = !(getenv("RHO_CONV_M16") && atoi(getenv("RHO_CONV_M16")) == 0);
-    const bool m16 = m16_env && d.dtype == RHO_BF16 && taps > 1 && d.sh == 1 && d.sw == 1 && !d.up_h && !d.up_w;
-    if (d.dtype == RHO_BF16) return launch_taps<bf16_raw>(d, k, BM, t.NP, grid, lds, m16, st);
+    if (d.dtype == RHO_BF16) return launch_taps<bf16_raw>(d, k, BM, t.NP, grid, lds, m16 && m16_env, st);
     return launch_taps<float>(d, k, BM, t.NP, grid, lds, false, st);
 }
 

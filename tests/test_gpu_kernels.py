@@ -432,3 +432,26 @@ def test_im2col_taps_and_tap_gather_sum(ops):
                     tap += 1
         assert torch.allclose(o.cpu().view(N, D, H, W), acc, rtol=1e-6, atol=1e-6)
     assert L.rho_im2col_taps(xd.data_ptr(), out.data_ptr(), 0, 1, 1, 1, 1, 8, 1, 1, 3, 32, hip.stream()) != 0      # bf16 only
+
+
+WIDE_CONV = [((1, 1, 3), (2, 1, 1, 4096), 64, 64), ((1, 1, 3), (2, 1, 1, 4096), 96, 64), ((1, 1, 3), (2, 1, 1, 4096), 64, 128),
+             ((1, 1, 3), (2, 1, 1, 2048), 256, 128), ((1, 3, 3), (2, 1, 64, 64), 128, 128), ((1, 3, 3), (2, 1, 32, 32), 256, 256),
+             ((3, 3, 3), (2, 16, 16, 16), 128, 128), ((3, 3, 3), (1, 8, 16, 16), 256, 128)]
+
+
+@pytest.mark.parametrize("kernel,shape,cin,cout", WIDE_CONV, ids=[f"{'x'.join(map(str, c[0]))}-{c[2]}to{c[3]}" for c in WIDE_CONV])
+def test_conv_bf16_every_tap_count_and_cout_tile(ops, kernel, shape, cin, cout):
+    """The 16x16x32 variants by tap count (3 / 9 / 27) and cout tile (64: barrier per tap, 3-slot weight ring; 128: three taps per
+    barrier and a 9-slot ring where 9 divides the taps of a chunk, else per tap), several channel chunks deep - against torch's fp32
+    convolution of the same bf16-rounded operands.  Tolerance: relative l2 <= 4e-3 (bf16 output rounding is 2^-9 per element)."""
+    N, D, H, W = shape
+    x = det_normal((N, D, H, W, cin), "wc_x").to(DEV).to(torch.bfloat16)
+    wt = det_normal((cout, cin) + tuple(kernel), "wc_w").to(DEV) * 0.05
+    b = det_normal((cout,), "wc_b").to(DEV)
+    w = ops.prep_conv_weight(wt, torch.bfloat16)
+    y = torch.empty(N, D, H, W, cout, device=DEV, dtype=torch.bfloat16)
+    d = ops.make_conv_desc(x, None, w, b, kernel=tuple(kernel), cout=cout, split=cout, y=y, y2=None)
+    assert "M16=1" in ops.conv_variant(d) and f"BM={min(cout, 128)}" in ops.conv_variant(d)
+    ops.conv_launch(d)
+    ref = F.conv3d(x.float().permute(0, 4, 1, 2, 3), wt.to(torch.bfloat16).float(), b, padding=tuple(k // 2 for k in kernel)).permute(0, 2, 3, 4, 1)
+    assert rel_l2(y.float(), ref) <= 4e-3

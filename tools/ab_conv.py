@@ -9,6 +9,7 @@ from rho_diffusion_amd.engine import ops
 
 dev = "cuda"
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+UP = {"128->128 up @64x32x32": (64, 32, 32, 128, 128), "512->512 up @64x8x8": (64, 8, 8, 512, 512)}
 cases = {"64->64 @64^3 +pre": (64, 64, 64, 64, 64, True), "64->64 @64^3": (64, 64, 64, 64, 64, False), "192->64 @64^3 +pre": (64, 64, 64, 192, 64, True),
          "128->128 @64x32x32 +pre": (64, 32, 32, 128, 128, True), "128->128 @64x32x32": (64, 32, 32, 128, 128, False),
          "256->256 @64x16x16 +pre": (64, 16, 16, 256, 256, True), "512->512 @64x8x8 +pre": (64, 8, 8, 512, 512, True),
@@ -16,7 +17,9 @@ cases = {"64->64 @64^3 +pre": (64, 64, 64, 64, 64, True), "64->64 @64^3": (64, 6
 libs = {"tree": C.CDLL(os.path.join(R0, "rho_diffusion_amd/librho_hip.so"))}
 for extra in os.environ.get("AB_EXTRA", "").split():
     libs[os.path.basename(extra)] = C.CDLL(os.path.join(R0, extra))
+cases.update({k: v + (False,) for k, v in UP.items()})
 for name, (D, H, W, cin, cout, pre) in cases.items():
+    up = name in UP
     row = []
     for zero in (False, True):
         sc = 0.0 if zero else 0.5
@@ -25,10 +28,11 @@ for name, (D, H, W, cin, cout, pre) in cases.items():
         b = torch.zeros(cout, device=dev)
         a_ = (1 + 0.3 * torch.randn(N, cin, device=dev)) * (0.0 if zero else 1.0)
         b_ = 0.2 * torch.randn(N, cin, device=dev) * (0.0 if zero else 1.0)
-        y = torch.empty(N, D, H, W, cout, device=dev, dtype=torch.bfloat16)
+        m = 2 if up else 1
+        y = torch.empty(N, D, H * m, W * m, cout, device=dev, dtype=torch.bfloat16)
         d = ops.make_conv_desc(x, None, w, b, kernel=(3, 3, 3), cout=cout, split=cout, y=y, y2=None, pre_a=a_ if pre else None,
-                               pre_b=b_ if pre else None, pre_silu=pre)
-        fl = 2.0 * N * D * H * W * cin * cout * 27
+                               pre_b=b_ if pre else None, pre_silu=pre, up_hw=(1, 1) if up else (0, 0))
+        fl = 2.0 * N * D * H * W * m * m * cin * cout * 27
         for k, lib in libs.items():
             fn = lib.rho_conv_nd_fwd
             fn.argtypes = [C.c_void_p, C.c_void_p]; fn.restype = C.c_int
