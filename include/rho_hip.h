@@ -195,6 +195,16 @@ typedef struct rho_conv_desc {
     float* stats;          /* optional: per-tile channel sums of the stored (rounded) output, float32
                               [N][tiles][2][split] with tiles = rho_conv_stats_tiles(desc): row 0 = sum, row 1 = sum of
                               squares over the tile's positions; combined in fixed order by rho_gn_finalize2 */
+    /* --- GroupNorm BACKWARD reduction fused into a dgrad launch (the output is d act(a * x + b), x the forward input): with
+     * gnb_x1 set, `stats` receives per tile and channel  row 0 = sum of dz,  row 1 = sum of dz * x  (dz = output * act'(a x + b),
+     * the output as stored) instead of the output's own moments: what rho_gn_bwd_reduce reads two tensors to compute
+     * (rho_gn_bwd_finalize with fmt = 1 takes this layout).  Replaces the reductions of GroupNorm32's autograd backward. */
+    const void* gnb_x1;    /* forward input, channels-last, first gnb_c1 channels of the output's `split` */
+    const void* gnb_x2;    /* second concat source (split - gnb_c1 channels) or NULL */
+    int32_t gnb_c1;
+    int32_t gnb_silu;      /* act = SiLU (else identity) */
+    const float* gnb_a;    /* [N][split] folded affine of the forward prologue (pre_a / pre_b of the forward conv) */
+    const float* gnb_b;
 } rho_conv_desc;
 
 /* n-D convolution, zero padding k/2, as an LDS-halo-staged implicit GEMM on MFMA.
@@ -270,14 +280,16 @@ int rho_prep_conv_weight_dgrad(const float* w, void* out, int dtype, int64_t cou
 /* Backward of act(GroupNorm32(x) * (1 + scale) + shift) (layers.py:71-74 + unet_v2.py:285-289), recomputed
  * from x, the saved stats and the folded affine (a, b):
  *   reduce  : per-(n, c) sums of g*act'(u) and g*act'(u)*xhat            (one pass over g and x)
- *   finalize: dgamma / dbeta (summed over samples, optionally accumulated), FiLM gradients dscale / dshift
+ *   finalize: (fmt 0: the reduce pass's partials, nblk = rho_gn_nblk(s); fmt 1: the per-tile sums of dz and dz * x a dgrad
+ *             launch wrote through rho_conv_desc.gnb_*, [N][nblk tiles][2][C] - the reduce pass is not run then)
+ *             dgamma / dbeta (summed over samples, optionally accumulated), FiLM gradients dscale / dshift
  *             ([N, C] at row stride dfilm_stride), and the coefficients cA [N,C], cP / cQ [N,32] of pass 3;
  *             work_nc2 is float32 [2][N][C] scratch
  *   apply   : dx = cA*g*act'(u) + cP + cQ*x, written (or accumulated) into the one or two source gradients. */
 int rho_gn_bwd_reduce(const void* g, const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t n,
                       int64_t s, const float* a, const float* b, const float* stats, int pre_silu, float* partials,
                       void* stream);
-int rho_gn_bwd_finalize(const float* partials, int64_t n, int64_t c, int64_t s, int64_t nblk, const float* gamma,
+int rho_gn_bwd_finalize(const float* partials, int64_t n, int64_t c, int64_t s, int64_t nblk, int fmt, const float* gamma,
                         const float* beta, const float* scale, int64_t film_stride, const float* stats,
                         float* work_nc2, float* dgamma, float* dbeta, int accumulate, float* dscale, float* dshift,
                         int64_t dfilm_stride, float* cA, float* cP, float* cQ, void* stream);

@@ -33,6 +33,11 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float silu_f(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
+// d silu(u) / du
+__device__ __forceinline__ float dsilu_f(float u) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * u));
+    return s * (1.0f + u * (1.0f - s));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

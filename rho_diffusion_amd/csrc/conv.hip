@@ -59,6 +59,12 @@ struct ConvK {
     float inv_ihw, inv_iw;  // 1 / (IH*IW), 1 / IW: exact small-integer division through one float multiply
     int cofast;           // cout tiles of one position tile on consecutive launch slots of one XCD
     int coef_off;         // > 0: byte offset in LDS of the staged prologue coefficients [2][cin] (3-D tiles: one sample per tile)
+    // GroupNorm backward reduction fused into a dgrad launch (rho_conv_desc.gnb_*): stats <- per-tile sums of dz and dz * x
+    const char* gnb_x1;
+    const char* gnb_x2;
+    const float* gnb_a;
+    const float* gnb_b;
+    int gnb_c1, gnb_silu;
 };
 
 // floor(a / d) for 0 <= a < 2^20 with inv = 1.0f / d: (a + 0.5) * inv is at least 0.5 / d away from an integer, the
@@ -792,9 +798,24 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
             static_assert(256 * PPR % NTHR == 0, "whole items per thread");
             long long eoff[NIT];
             uint4 rres[NIT];
+            uint4 gx[NIT];                                  // gnb: this thread's piece of the forward input at its output positions
             float bia[PE];                                  // bias (+ the per-sample additive term, 3-D: one sample per tile)
+            float gna[PE], gnb[PE];                         // gnb: folded affine of the forward prologue, this thread's channels
+            const bool gnb_on = p.gnb_x1 != nullptr;
             {
                 const int piece = tid % PPR;
+                const int gco = co0 + piece * PE;           // the piece lies in one concat source (widths are multiples of 32)
+                const bool g_first = gco < p.gnb_c1;
+                const char* const gsrc = g_first ? p.gnb_x1 : p.gnb_x2;
+                const int gcs = g_first ? p.gnb_c1 : p.split - p.gnb_c1, gch = g_first ? gco : gco - p.gnb_c1;
+                if (gnb_on) {
+                    const int nsg = n + bt / p.tps;         // the tile's sample (statistics are only fused for one-sample tiles)
+#pragma unroll
+                    for (int e = 0; e < PE; ++e) {
+                        gna[e] = p.gnb_a[(size_t)nsg * p.split + gco + e];
+                        gnb[e] = p.gnb_b[(size_t)nsg * p.split + gco + e];
+                    }
+                }
 #pragma unroll
                 for (int q4 = 0; q4 < PE / 4; ++q4) {
                     const float4 b4 = *reinterpret_cast<const float4*>(p.bias + co0 + piece * PE + q4 * 4);
@@ -821,6 +842,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                     rres[k] = make_uint4(0u, 0u, 0u, 0u);
                     if (ok && p.res != nullptr)
                         rres[k] = *reinterpret_cast<const uint4*>(p.res + ((size_t)L * p.split + co0 + piece * PE) * sizeof(T));
+                    gx[k] = make_uint4(0u, 0u, 0u, 0u);
+                    if (ok && gnb_on) gx[k] = *reinterpret_cast<const uint4*>(gsrc + ((size_t)L * gcs + gch) * sizeof(T));
                 }
             }
             __syncthreads();
@@ -874,10 +897,33 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                     *reinterpret_cast<float4*>(p.y + eo * 4) = make_float4(v[0], v[1], v[2], v[3]);
                 }
                 if (p.stats != nullptr) {
+                    if (gnb_on) {
+                        // dgrad of a conv behind GroupNorm (+SiLU): v = d act(a x + b) as stored; the norm's backward needs the
+                        // per-channel sums of dz = v * act'(a x + b) and of dz * x (rho_gn_bwd_finalize, fmt 1)
+                        float xv[PE];
+                        if constexpr (sizeof(T) == 2) {
+                            const uint4 q = gx[k];
+                            xv[0] = __uint_as_float(q.x << 16); xv[1] = __uint_as_float(q.x & 0xFFFF0000u);
+                            xv[2] = __uint_as_float(q.y << 16); xv[3] = __uint_as_float(q.y & 0xFFFF0000u);
+                            xv[4] = __uint_as_float(q.z << 16); xv[5] = __uint_as_float(q.z & 0xFFFF0000u);
+                            xv[6] = __uint_as_float(q.w << 16); xv[7] = __uint_as_float(q.w & 0xFFFF0000u);
+                        } else {
+                            const uint4 q = gx[k];
+                            xv[0] = __uint_as_float(q.x); xv[1] = __uint_as_float(q.y); xv[2] = __uint_as_float(q.z); xv[3] = __uint_as_float(q.w);
+                        }
 #pragma unroll
-                    for (int e = 0; e < PE; ++e) {
-                        ssum[e] += v[e];
-                        ssq[e] = fmaf(v[e], v[e], ssq[e]);
+                        for (int e = 0; e < PE; ++e) {
+                            float dz = v[e];
+                            if (p.gnb_silu) dz *= dsilu_f(fmaf(gna[e], xv[e], gnb[e]));
+                            ssum[e] += dz;
+                            ssq[e] = fmaf(dz, xv[e], ssq[e]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < PE; ++e) {
+                            ssum[e] += v[e];
+                            ssq[e] = fmaf(v[e], v[e], ssq[e]);
+                        }
                     }
                 }
             }
@@ -1162,6 +1208,14 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
     if (d.stats) {
         if (tps <= 0) return RHO_E_ARG;
         k.stats = d.stats; k.tps = (int)tps;
+    }
+    k.gnb_x1 = nullptr;
+    if (d.gnb_x1) {
+        if (!d.stats || !d.gnb_a || !d.gnb_b || d.gnb_c1 <= 0 || d.gnb_c1 > d.split || d.gnb_c1 % 32 || (d.split - d.gnb_c1) % 32 ||
+            ((d.gnb_c1 < d.split) != (d.gnb_x2 != nullptr)))
+            return RHO_E_ARG;
+        k.gnb_x1 = (const char*)d.gnb_x1; k.gnb_x2 = (const char*)d.gnb_x2; k.gnb_a = d.gnb_a; k.gnb_b = d.gnb_b;
+        k.gnb_c1 = d.gnb_c1; k.gnb_silu = d.gnb_silu;
     }
     size_t lds = (size_t)t.NP * PITCH + (size_t)WSLOTS * BM * PITCH;
     k.coef_off = 0;

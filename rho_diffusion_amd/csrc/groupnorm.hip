@@ -308,10 +308,6 @@ extern "C" int rho_gn_finalize2(const float* p1, int fmt1, int64_t nblk1, int64_
 // Per-(n, c) sums R1 = sum_pos gq and R2 = sum_pos gq*xhat (pass 1, same partial layout as the
 // forward statistics) give every parameter / FiLM gradient and the group means, so pass 2 is a pure
 // elementwise   dx = A[n,c]*gq + P[n,grp] + Q[n,grp]*x .
-__device__ __forceinline__ float dsilu_f(float u) {
-    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * u));
-    return s * (1.0f + u * (1.0f - s));
-}
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_gn_bwd_reduce(const T* __restrict__ g, const T* __restrict__ x1, int c1,
@@ -422,7 +418,7 @@ extern "C" int rho_gn_bwd_reduce(const void* g, const void* x1, int64_t c1, cons
 
 // grid (n, 8): a workgroup owns 4 groups (4 * cpg <= 256 channels) of one sample: totals over the position blocks (KP
 // lanes per channel, fixed order), group sums, per-sample parameter-gradient rows and the apply coefficients
-__global__ __launch_bounds__(256) void k_gn_bwd_finalize(const float* __restrict__ partials, int c, int64_t s, int nblk,
+__global__ __launch_bounds__(256) void k_gn_bwd_finalize(const float* __restrict__ partials, int c, int64_t s, int nblk, int fmt,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ scale, int64_t film_stride,
                                                          const float* __restrict__ stats, float* __restrict__ dgamma_n,
@@ -443,10 +439,19 @@ __global__ __launch_bounds__(256) void k_gn_bwd_finalize(const float* __restrict
     if (kp < KP) {
         const int ch = ch0 + cl;
         const int o = ch >> 3, j = ch & 7;
-        for (int k = kp; k < nblk; k += KP) {
-            const float* p = partials + (((int64_t)n * nblk + k) * OCT + o) * 16;
-            a1 += (double)p[j];
-            a2 += (double)p[8 + j];
+        if (fmt == 0) {
+            for (int k = kp; k < nblk; k += KP) {
+                const float* p = partials + (((int64_t)n * nblk + k) * OCT + o) * 16;
+                a1 += (double)p[j];
+                a2 += (double)p[8 + j];
+            }
+        } else {
+            // per-tile sums written by a dgrad launch (rho_conv_desc.gnb_*): [n][tile][2][c], second row = sum of dz * x (raw x)
+            for (int k = kp; k < nblk; k += KP) {
+                const float* p = partials + ((int64_t)n * nblk + k) * 2 * c + ch;
+                a1 += (double)p[0];
+                a2 += (double)p[c];
+            }
         }
     }
     l1[tid] = a1;
@@ -455,6 +460,11 @@ __global__ __launch_bounds__(256) void k_gn_bwd_finalize(const float* __restrict
     if (tid < CB) {
         double t1 = 0.0, t2 = 0.0;
         for (int q = 0; q < KP; ++q) { t1 += l1[q * CB + tid]; t2 += l2[q * CB + tid]; }
+        if (fmt != 0) {                                   // sum dz * xhat = rstd * (sum dz * x - mean * sum dz)
+            const int grp = (ch0 + tid) / cpg;
+            const double mean = (double)stats[((int64_t)n * 32 + grp) * 2 + 0], rstd = (double)stats[((int64_t)n * 32 + grp) * 2 + 1];
+            t2 = rstd * (t2 - mean * t1);
+        }
         r1s[tid] = (float)t1;
         r2s[tid] = (float)t2;
     }
@@ -509,18 +519,18 @@ __global__ void k_sum_over_n(const float* __restrict__ in, float* __restrict__ o
     out[ch] = accumulate ? out[ch] + acc : acc;
 }
 
-extern "C" int rho_gn_bwd_finalize(const float* partials, int64_t n, int64_t c, int64_t s, int64_t nblk, const float* gamma,
+extern "C" int rho_gn_bwd_finalize(const float* partials, int64_t n, int64_t c, int64_t s, int64_t nblk, int fmt, const float* gamma,
                                    const float* beta, const float* scale, int64_t film_stride, const float* stats,
                                    float* work_nc2, float* dgamma, float* dbeta, int accumulate, float* dscale, float* dshift,
                                    int64_t dfilm_stride, float* cA, float* cP, float* cQ, void* stream) {
     if (!partials || !gamma || !beta || !stats || !work_nc2 || !dgamma || !dbeta || !cA || !cP || !cQ || n <= 0 || c <= 0 ||
-        c % 32 != 0 || c > 2048 || (dscale && !dshift))
+        c % 32 != 0 || c > 2048 || (dscale && !dshift) || (fmt != 0 && fmt != 1) || nblk <= 0)
         return RHO_E_ARG;
     float* dg_n = work_nc2;
     float* db_n = work_nc2 + n * c;
     if (n > 65535) return RHO_E_SHAPE;
-    hipLaunchKernelGGL(k_gn_bwd_finalize, dim3((unsigned)n, 8), dim3(256), 0, as_stream(stream), partials, (int)c, s, (int)nblk, gamma,
-                       beta, scale, film_stride, stats, dg_n, db_n, dscale, dshift, dfilm_stride, cA, cP, cQ);
+    hipLaunchKernelGGL(k_gn_bwd_finalize, dim3((unsigned)n, 8), dim3(256), 0, as_stream(stream), partials, (int)c, s, (int)nblk, fmt,
+                       gamma, beta, scale, film_stride, stats, dg_n, db_n, dscale, dshift, dfilm_stride, cA, cP, cQ);
     RHO_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_sum_over_n2, dim3((unsigned)((c + 255) / 256), 2), dim3(256), 0, as_stream(stream), dg_n, dgamma, db_n, dbeta,
                        (int)n, (int)c, accumulate);

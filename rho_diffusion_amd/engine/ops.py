@@ -382,7 +382,7 @@ def gn_bwd(g: Tensor, x1: Tensor, x2: Optional[Tensor], a: Tensor, b: Tensor, st
     p = lambda t: t if isinstance(t, int) or t is None else t.data_ptr()  # noqa: E731
     check(L.rho_gn_bwd_reduce(ptr(g), ptr(x1), c1, ptr(x2), c2, dt, N, S, ptr(a), ptr(b), ptr(stats), int(pre_silu), ptr(ws["part"]),
                               stream()), "rho_gn_bwd_reduce")
-    check(L.rho_gn_bwd_finalize(ptr(ws["part"]), N, Cc, S, nblk, ptr(gamma), ptr(beta), p(scale), film_stride, ptr(stats),
+    check(L.rho_gn_bwd_finalize(ptr(ws["part"]), N, Cc, S, nblk, 0, ptr(gamma), ptr(beta), p(scale), film_stride, ptr(stats),
                                 ptr(ws["work"]), ptr(dgamma), ptr(dbeta), int(acc_params), p(dscale), p(dshift), dfilm_stride,
                                 ptr(ws["cA"]), ptr(ws["cP"]), ptr(ws["cQ"]), stream()), "rho_gn_bwd_finalize")
     check(L.rho_gn_bwd_apply(ptr(g), ptr(x1), c1, ptr(x2), c2, dt, N, S, ptr(a), ptr(b), int(pre_silu), ptr(ws["cA"]), ptr(ws["cP"]),

@@ -374,6 +374,10 @@ class _Plan:
         self.train = train
         self.materialize_act = os.environ.get("RHO_TRAIN_MATERIALIZE", "1") != "0"    # memory-for-time trade of training plans
         self.materialize_min_cout = int(os.environ.get("RHO_MATERIALIZE_MIN_COUT", "256"))
+        # backward: GroupNorm's reductions (sum dz, sum dz * x) in the epilogue of the dgrad launch that produces dz (A/B switch)
+        # - from RHO_FUSE_GN_BWD channels up (0 = never): on the 64-channel layers the extra epilogue VALU work (one sigmoid per
+        # element) costs the issue-bound narrow tiles more than the separate reduce pass it replaces
+        self.fuse_gn_bwd = int(os.environ.get("RHO_FUSE_GN_BWD", "128"))
         m = eng.model
         dt = eng.dtype
         dtc = hip.dtype_code(dt)
@@ -773,9 +777,10 @@ class _Plan:
             if xact is not None:
                 pool.put(xact)
 
-        def gn_backward(pre, pre_silu, x1, x2, dact):
+        def gn_backward(pre, pre_silu, x1, x2, dact, fused=None):
             """dact = gradient of act(GroupNorm(x) * (1 + scale) + shift): reduce / finalize / apply into the gradients of x1 (, x2),
-            the norm's parameters and the FiLM rows."""
+            the norm's parameters and the FiLM rows.  ``fused`` = (tile sums, tiles per sample) when the dgrad launch that produced
+            dact already reduced dz and dz * x in its epilogue (rho_conv_desc.gnb_*): the reduce pass is skipped."""
             c1 = x1.shape[-1]
             c2 = x2.shape[-1] if x2 is not None else 0
             norm = pre["norm"]
@@ -793,12 +798,16 @@ class _Plan:
                 fstride = film_stride
                 dscale = self.dfilm.data_ptr() + 4 * pre["film_off"]
                 dshift = self.dfilm.data_ptr() + 4 * (pre["film_off"] + Cc)
-            a1 = (ptr(dact), ptr(x1), c1, ptr(x2), c2, dtc, N_, S_, ptr(pre["a"]), ptr(pre["b"]), ptr(pre["st"]),
-                  int(pre_silu), ptr(pre["part"]))
-            emit(lambda s, a=a1: L.rho_gn_bwd_reduce(*a, s), "gn_bwd_reduce", nbytes=2.0 * esz * N_ * S_ * Cc)
+            if fused is None:
+                a1 = (ptr(dact), ptr(x1), c1, ptr(x2), c2, dtc, N_, S_, ptr(pre["a"]), ptr(pre["b"]), ptr(pre["st"]),
+                      int(pre_silu), ptr(pre["part"]))
+                emit(lambda s, a=a1: L.rho_gn_bwd_reduce(*a, s), "gn_bwd_reduce", nbytes=2.0 * esz * N_ * S_ * Cc)
+                part_ptr, part_n, fmt = ptr(pre["part"]), pre["nblk"], 0
+            else:
+                part_ptr, part_n, fmt = ptr(fused[0]), fused[1], 1
             emit(lambda s, pre=pre, norm=norm, scale=scale, fstride=fstride, work=work, dscale=dscale, dshift=dshift,
-                 cA=cA, cP=cP, cQ=cQ, N_=N_, Cc=Cc, S_=S_: L.rho_gn_bwd_finalize(
-                     ptr(pre["part"]), N_, Cc, S_, pre["nblk"], ptr(norm.weight), ptr(norm.bias), scale, fstride, ptr(pre["st"]),
+                 cA=cA, cP=cP, cQ=cQ, N_=N_, Cc=Cc, S_=S_, part_ptr=part_ptr, part_n=part_n, fmt=fmt: L.rho_gn_bwd_finalize(
+                     part_ptr, N_, Cc, S_, part_n, fmt, ptr(norm.weight), ptr(norm.bias), scale, fstride, ptr(pre["st"]),
                      ptr(work), pgrad(norm.weight), pgrad(norm.bias), 1, dscale, dshift, film_stride, ptr(cA), ptr(cP),
                      ptr(cQ), s), "gn_bwd_finalize")
             a3 = (ptr(dact), ptr(x1), c1, ptr(x2), c2, dtc, N_, S_, ptr(pre["a"]), ptr(pre["b"]), int(pre_silu),
@@ -824,12 +833,24 @@ class _Plan:
                 tshape = (N, Do, Ho, Wo, cin) if node["up_hw"] != (0, 0) else tuple(x1.shape[:4]) + (cin,)
                 dact = pool.get(tshape, dt)       # gradient of the activated / upsampled tensor
                 d = ops.make_conv_desc(dY, None, cw.wd, cw.zero_bias, split=cin, y=dact, y2=None, **common)
+                fused = None
+                if pre is not None and self.fuse_gn_bwd > 0 and cin >= self.fuse_gn_bwd:
+                    # the norm's backward reductions ride in this launch's epilogue where a tile lies in one sample
+                    tiles = int(L.rho_conv_stats_tiles(C.byref(d)))
+                    if tiles > 0:
+                        sbuf = pool.get((x1.shape[0] * tiles * 2 * cin,), torch.float32)
+                        d.stats = sbuf.data_ptr()
+                        d.gnb_x1, d.gnb_x2, d.gnb_c1 = ptr(x1), ptr(x2), c1
+                        d.gnb_a, d.gnb_b, d.gnb_silu = ptr(pre["a"]), ptr(pre["b"]), int(node["pre_silu"])
+                        fused = (sbuf, tiles)
                 self.keep.append(d)
                 self.fwd_descs.append(d)
                 emit(lambda s, d=d: L.rho_conv_nd_fwd(C.byref(d), s), "dgrad",
                      flops=2.0 * (dact.numel() // cin) * cin * cw.cout * cw.taps, nbytes=float(esz) * (dY.numel() + dact.numel()))
                 if pre is not None:
-                    gn_backward(pre, node["pre_silu"], x1, x2, dact)
+                    gn_backward(pre, node["pre_silu"], x1, x2, dact, fused)
+                    if fused is not None:
+                        pool.put(fused[0])
                 else:   # upsample: sum the 2x2 (1x2) children
                     g1, acc1 = gradbuf(x1)
                     a = (ptr(dact), ptr(g1), dtc, x1.shape[0] * x1.shape[1], x1.shape[2], x1.shape[3], x1.shape[4],
