@@ -807,8 +807,20 @@ static int wgrad_impl(const rho_conv_desc* dp, const void* dy, int64_t dy_width,
     if (tiles > 0x7FFFFFFFLL) return RHO_E_SHAPE;
     k.tiles_total = (int)tiles;
     // enough workgroups to fill 256 CUs, long enough slabs to amortise the 27x64x32 fp32 flush
+    // One workgroup per CU (144 KB of LDS) and equal slabs: the launch runs in rounds of n_cu workgroups.  Pick the slab count so
+    // that splits x pairs fills 3..6 whole rounds (was ceil(1024 / pairs): 6 pairs -> 1026 workgroups = a fifth round of two,
+    // 20 % of the launch, on every layer whose channel count is 3 * 2^k - the concatenated inputs of the output blocks).
     const int pairs = cdiv(d.coutp, COT) * (cin / CK);
-    int splits = cdiv(1024, pairs);
+    static const int n_cu = []() { hipDeviceProp_t pr; int dev = 0; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
+    int splits = cdiv(4 * n_cu, pairs);
+    double best = -1.0;
+    for (int r = 3; r <= 6; ++r) {
+        const int sp = (r * n_cu) / pairs;
+        if (sp < 1) continue;
+        const long long total = (long long)sp * pairs;
+        const double eff = (double)total / (double)(cdiv((int)total, n_cu) * n_cu) - 0.002 * (r > 4 ? r - 4 : 4 - r);
+        if (eff > best) { best = eff; splits = sp; }
+    }
     if (splits < 1) splits = 1;
     if (splits > k.tiles_total) splits = k.tiles_total;
     k.tiles_per_block = cdiv(k.tiles_total, splits);

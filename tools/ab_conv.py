@@ -15,6 +15,8 @@ cases = {"64->64 @64^3 +pre": (64, 64, 64, 64, 64, True), "64->64 @64^3": (64, 6
          "256->256 @64x16x16 +pre": (64, 16, 16, 256, 256, True), "512->512 @64x8x8 +pre": (64, 8, 8, 512, 512, True),
          "512->512 @64x8x8": (64, 8, 8, 512, 512, False)}
 libs = {"tree": C.CDLL(os.path.join(R0, "rho_diffusion_amd/librho_hip.so"))}
+libs["tree"].rho_conv_stats_tiles.restype = C.c_int64
+libs["tree"].rho_conv_stats_tiles.argtypes = [C.c_void_p]
 for extra in os.environ.get("AB_EXTRA", "").split():
     libs[os.path.basename(extra)] = C.CDLL(os.path.join(R0, extra))
 cases.update({k: v + (False,) for k, v in UP.items()})
@@ -30,8 +32,14 @@ for name, (D, H, W, cin, cout, pre) in cases.items():
         b_ = 0.2 * torch.randn(N, cin, device=dev) * (0.0 if zero else 1.0)
         m = 2 if up else 1
         y = torch.empty(N, D, H * m, W * m, cout, device=dev, dtype=torch.bfloat16)
+        feats = os.environ.get("AB_FEATS", "")                      # "s" = fused output statistics, "r" = residual input
+        res = torch.randn_like(y) if "r" in feats else None
         d = ops.make_conv_desc(x, None, w, b, kernel=(3, 3, 3), cout=cout, split=cout, y=y, y2=None, pre_a=a_ if pre else None,
-                               pre_b=b_ if pre else None, pre_silu=pre, up_hw=(1, 1) if up else (0, 0))
+                               pre_b=b_ if pre else None, pre_silu=pre, up_hw=(1, 1) if up else (0, 0), res=res)
+        if "s" in feats:
+            tiles = int(libs["tree"].rho_conv_stats_tiles(C.byref(d)))
+            sbuf = torch.empty(N * tiles * 2 * cout, device=dev)
+            d.stats = sbuf.data_ptr()
         fl = 2.0 * N * D * H * W * m * m * cin * cout * 27
         for k, lib in libs.items():
             fn = lib.rho_conv_nd_fwd
