@@ -195,6 +195,12 @@ typedef struct rho_conv_desc {
     float* stats;          /* optional: per-tile channel sums of the stored (rounded) output, float32
                               [N][tiles][2][split] with tiles = rho_conv_stats_tiles(desc): row 0 = sum, row 1 = sum of
                               squares over the tile's positions; combined in fixed order by rho_gn_finalize2 */
+    /* --- sub-pixel phases of a conv behind a nearest x2 upsample (Upsample, unet_v2.py:122-134): on an upsampled axis the three
+     * taps of output row 2i + a read only two source rows (a = 0: rows i-1, i with weights w0, w1 + w2; a = 1: rows i, i+1 with
+     * w0 + w1, w2), so one launch per parity runs a 2-tap axis (kh / kw = 2, weights from rho_prep_conv_weight_phase) on the
+     * SOURCE tensor and writes every second output row / column: 12 instead of 27 taps in 3-D.  ph_h / ph_w: 0 = axis not
+     * upsampled, 1 / 2 = parity 0 / 1.  y (and res, stats) describe the full-resolution output [N, D, 2H, 2W, cout]. */
+    int32_t ph_h, ph_w;
     /* --- GroupNorm BACKWARD reduction fused into a dgrad launch (the output is d act(a * x + b), x the forward input): with
      * gnb_x1 set, `stats` receives per tile and channel  row 0 = sum of dz,  row 1 = sum of dz * x  (dz = output * act'(a x + b),
      * the output as stored) instead of the output's own moments: what rho_gn_bwd_reduce reads two tensors to compute
@@ -213,6 +219,12 @@ typedef struct rho_conv_desc {
  * :323,:331 with the residual of :342; stem :535; head :679-683) with the GroupNorm affine +
  * FiLM + SiLU (:212-216, :285-289) applied while the halo tile is staged. */
 int rho_conv_nd_fwd(const rho_conv_desc* desc, void* stream);
+
+/* Weights of one sub-pixel phase (see rho_conv_desc.ph_h): from the fp32 parameter [cout][cin][kd][kh][kw] (kh / kw = 3 on a
+ * phased axis) to the launch layout [kd * kh' * kw' taps][coutp][cinp] with the two taps of a phased axis summed as described
+ * there; ph_h / ph_w as in the descriptor. */
+int rho_prep_conv_weight_phase(const float* w, void* out, int dtype, int64_t cout, int64_t cin, int kd, int kh, int kw, int ph_h,
+                               int ph_w, int64_t coutp, int64_t cinp, void* stream);
 
 /* Number of output tiles per sample the launch of `desc` uses (the middle extent of desc->stats), or 0 when fused
  * statistics are not available for this geometry (channel-major outputs, tiles that straddle samples: 1-D / 2-D

@@ -59,6 +59,10 @@ struct ConvK {
     float inv_ihw, inv_iw;  // 1 / (IH*IW), 1 / IW: exact small-integer division through one float multiply
     int cofast;           // cout tiles of one position tile on consecutive launch slots of one XCD
     int coef_off;         // > 0: byte offset in LDS of the staged prologue coefficients [2][cin] (3-D tiles: one sample per tile)
+    // Sub-pixel phase of a conv behind a nearest x2 upsample (rho_conv_desc.ph_h / ph_w): taps start pad_h / pad_w rows before the
+    // output position; the launch writes output row oh * oy_mul + oy_add of a tensor with Ho_out x Wo_out rows per depth slice
+    int pad_h, pad_w, oy_mul, oy_add, ox_mul, ox_add, Ho_out, Wo_out;
+    int stats_off;        // first statistics tile of this launch within the tps tiles of a sample
     // GroupNorm backward reduction fused into a dgrad launch (rho_conv_desc.gnb_*): stats <- per-tile sums of dz and dz * x
     const char* gnb_x1;
     const char* gnb_x2;
@@ -157,8 +161,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
     const int n = blockIdx.z;
     const int od0 = td_i * p.TD, oh0 = th_i * p.TH, ow0 = tw_i * p.TW;
     const int gd_base = od0 - (KD / 2);
-    const int gh_base = p.up_h ? (oh0 / 2 - 1) : (oh0 * p.sh - (KH / 2));
-    const int gw_base = p.up_w ? (ow0 / 2 - 1) : (ow0 * p.sw - (KW / 2));
+    const int gh_base = p.up_h ? (oh0 / 2 - 1) : (oh0 * p.sh - p.pad_h);
+    const int gw_base = p.up_w ? (ow0 / 2 - 1) : (ow0 * p.sw - p.pad_w);
 
     // ---- halo slots owned by this thread: global linear input position (or -1 = zero padding,
     //      -2 = beyond the tile) and sample index for the prologue coefficients
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
             // two column-tile pairs in an order that alternates with the tap.  Five 2-fragment register sets (a01, a23, bS and
             // bF[2]); every set is read from LDS two phases (>= 128 MFMA cycles) before its first use:
             //   phase 0 reads a23 (phase 2) | 1 reads the next tap's F | 2 reads the next tap's a01 | 3 reads the next tap's S.
-            static_assert(MT == 2 && NS % 2 == 1, "M16 tap schedule: 64 couts per wave, odd tap count");
+            static_assert(MT == 2, "M16 tap schedule: 64 couts per wave");
             typedef float f32x4_t __attribute__((ext_vector_type(4)));
             typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
             u32x4_t a01[2], a23[2], bS[2][2], bF[2][2];
@@ -837,7 +841,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                     const int pd = pp >> (p.lgTW + p.lgTH);
                     const int od = od0 + pd, oh = oh0 + ph, ow = ow0 + pw;
                     const bool ok = od < p.Do && oh < p.Ho && ow < p.Wo;
-                    const long long L = (((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
+                    const long long L = (((long long)n * p.Do + od) * p.Ho_out + (oh * p.oy_mul + p.oy_add)) * p.Wo_out + (ow * p.ox_mul + p.ox_add);
                     eoff[k] = ok ? L : -1;
                     rres[k] = make_uint4(0u, 0u, 0u, 0u);
                     if (ok && p.res != nullptr)
@@ -939,7 +943,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                 red[tid * (2 * PE) + PE + e] = ssq[e];
             }
             __syncthreads();
-            const int ns = n + bt / p.tps, ts = bt % p.tps;
+            const int ns = n + bt / p.tps, ts = bt % p.tps + p.stats_off;
             for (int item = tid; item < PPR * 2 * PE; item += NTHR) {
                 const int piece = item / (2 * PE), e2 = item % (2 * PE);
                 float accv = 0.0f;
@@ -1064,7 +1068,9 @@ int launch_one(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
 // np = halo positions of the chosen tile.  BM = 128 runs 8 waves (slots per thread: 5 for np <= 640, else 14).
 template <typename T, int KD, int KH, int KW>
 int launch_bm(const ConvK& k, int BM, int np, dim3 grid, size_t lds, bool m16, hipStream_t st) {
-    if constexpr (sizeof(T) == 2 && KD * KH * KW > 1) {
+    constexpr bool PHASE = (KH == 2 || KW == 2);     // sub-pixel phase kernels: stride 1, 2-tap axes - the small-halo variants only
+    if constexpr (PHASE) { if (np > 640) return RHO_E_SHAPE; }
+    if constexpr (sizeof(T) == 2 && KD * KH * KW > 1 && (KD * KH * KW) % 3 == 0) {
         // bf16, stride 1, no upsampling, regular halo: the 16x16x32 MFMA layout (holds a higher clock under load)
         if (m16 && np <= 640) {
             if (BM == 128) return launch_one<T, KD, KH, KW, 128, 5, 8, true>(k, grid, lds, st);
@@ -1073,12 +1079,12 @@ int launch_bm(const ConvK& k, int BM, int np, dim3 grid, size_t lds, bool m16, h
     }
     if (BM == 128) {
         if (np <= 640) return launch_one<T, KD, KH, KW, 128, 5, 8>(k, grid, lds, st);
-        return launch_one<T, KD, KH, KW, 128, 14, 8>(k, grid, lds, st);
+        if constexpr (!PHASE) return launch_one<T, KD, KH, KW, 128, 14, 8>(k, grid, lds, st);
     }
 #define RHO_CASE(bm)                                                                   \
     if (BM == bm) {                                                                    \
         if (np <= 640) return launch_one<T, KD, KH, KW, bm, 10, 4>(k, grid, lds, st);  \
-        return launch_one<T, KD, KH, KW, bm, 28, 4>(k, grid, lds, st);                 \
+        if constexpr (!PHASE) return launch_one<T, KD, KH, KW, bm, 28, 4>(k, grid, lds, st); \
     }
     RHO_CASE(32)
     RHO_CASE(64)
@@ -1092,6 +1098,10 @@ int launch_taps(const rho_conv_desc& d, const ConvK& k, int BM, int np, dim3 gri
     if (d.kd == 1 && d.kh == 3 && d.kw == 3) return launch_bm<T, 1, 3, 3>(k, BM, np, grid, lds, m16, st);
     if (d.kd == 1 && d.kh == 1 && d.kw == 3) return launch_bm<T, 1, 1, 3>(k, BM, np, grid, lds, m16, st);
     if (d.kd == 1 && d.kh == 1 && d.kw == 1) return launch_bm<T, 1, 1, 1>(k, BM, np, grid, lds, m16, st);
+    // sub-pixel phases of a conv behind a nearest x2 upsample (3-D / 2-D: both inner axes; 1-D: the last)
+    if (d.kd == 3 && d.kh == 2 && d.kw == 2) return launch_bm<T, 3, 2, 2>(k, BM, np, grid, lds, m16, st);
+    if (d.kd == 1 && d.kh == 2 && d.kw == 2) return launch_bm<T, 1, 2, 2>(k, BM, np, grid, lds, m16, st);
+    if (d.kd == 1 && d.kh == 1 && d.kw == 2) return launch_bm<T, 1, 1, 2>(k, BM, np, grid, lds, m16, st);
     return RHO_E_ARG;
 }
 
@@ -1117,18 +1127,30 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
     if ((d.up_h && d.sh != 1) || (d.up_w && d.sw != 1)) return RHO_E_ARG;
     if ((d.up_h && d.kh != 3) || (d.up_w && d.kw != 3)) return RHO_E_ARG;
     if (d.n <= 0 || d.d <= 0 || d.h <= 0 || d.w_ <= 0) return RHO_E_ARG;
+    // sub-pixel phases: a 2-tap axis at the source resolution, stride 1, the output rows of one parity
+    if (d.ph_h < 0 || d.ph_h > 2 || d.ph_w < 0 || d.ph_w > 2) return RHO_E_ARG;
+    if ((d.ph_h && (d.kh != 2 || d.sh != 1 || d.up_h || d.zs_h)) || (d.ph_w && (d.kw != 2 || d.sw != 1 || d.up_w || d.zs_w))) return RHO_E_ARG;
+    if ((!d.ph_h && d.kh == 2) || (!d.ph_w && d.kw == 2)) return RHO_E_ARG;
+    if ((d.ph_h || d.ph_w) && (d.split != d.cout || d.kd == 2)) return RHO_E_ARG;      // channels-last outputs only
 
     // output extents per sample (padding k/2).  Zero-stuffed input (dgrad of a stride-2 conv): the
     // virtual input and the output both have the forward conv's input extent out_h / out_w.
     const int hv = d.zs_h ? d.out_h : d.h, wv = d.zs_w ? d.out_w : d.w_;   // virtual input extents
-    const int ho = d.up_h ? d.h * 2 : (hv + 2 * (d.kh / 2) - d.kh) / d.sh + 1;
-    const int wo = d.up_w ? d.w_ * 2 : (wv + 2 * (d.kw / 2) - d.kw) / d.sw + 1;
+    // (phases: the launch's own output grid is the source grid; it lands on every second row / column of the real output)
+    const int ho = d.ph_h ? d.h : d.up_h ? d.h * 2 : (hv + 2 * (d.kh / 2) - d.kh) / d.sh + 1;
+    const int wo = d.ph_w ? d.w_ : d.up_w ? d.w_ * 2 : (wv + 2 * (d.kw / 2) - d.kw) / d.sw + 1;
+    const int ho_out = d.ph_h ? 2 * ho : ho, wo_out = d.ph_w ? 2 * wo : wo;
+    const int n_phase = (d.ph_h ? 2 : 1) * (d.ph_w ? 2 : 1);
+    const int phase_idx = (d.ph_h ? d.ph_h - 1 : 0) * (d.ph_w ? 2 : 1) + (d.ph_w ? d.ph_w - 1 : 0);
     const int dout = d.d;
 
     // axes that carry no kernel extent are merged with the batch so tiles stay full:
     //   1x1x1: everything is one long W axis;  1xkxk: depth*batch is the tile's depth axis.
     ConvK k{};
     int gridz = d.n;
+    k.pad_h = d.ph_h ? 2 - d.ph_h : d.kh / 2; k.pad_w = d.ph_w ? 2 - d.ph_w : d.kw / 2;
+    k.oy_mul = d.ph_h ? 2 : 1; k.oy_add = d.ph_h ? d.ph_h - 1 : 0;
+    k.ox_mul = d.ph_w ? 2 : 1; k.ox_add = d.ph_w ? d.ph_w - 1 : 0;
     if (d.kd == 1 && d.kh == 1 && d.kw == 1) {
         if (d.sh != 1 || d.sw != 1 || d.up_h || d.up_w) return RHO_E_ARG;
         k.D = 1; k.H = 1; k.W = d.n * d.d * d.h * d.w_;
@@ -1147,9 +1169,11 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
     if (d.zs_w) k.Ws = d.w_;
     k.zs_h = d.zs_h; k.zs_w = d.zs_w;
     k.y2_cl = d.y2_cl; k.res2 = (const char*)d.res2;
-    if ((long long)d.n * d.d * d.h * d.w_ >= (1LL << 31) || (long long)d.n * dout * ho * wo >= (1LL << 31)) return RHO_E_SHAPE;
+    if ((long long)d.n * d.d * d.h * d.w_ >= (1LL << 31) || (long long)d.n * dout * ho_out * wo_out >= (1LL << 31)) return RHO_E_SHAPE;
     k.S_in = (long long)d.d * d.h * d.w_;
-    k.S_out = (long long)dout * ho * wo;
+    k.S_out = (long long)dout * ho_out * wo_out;
+    k.Ho_out = (d.kd == 1 && d.kh == 1 && d.kw == 1) ? 1 : ho_out;
+    k.Wo_out = (d.kd == 1 && d.kh == 1 && d.kw == 1) ? k.Wo : wo_out;
 
     // cout tile
     int BM = 32;
@@ -1158,7 +1182,7 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
 
     const size_t lds_cap = 160 * 1024;
     const int taps = d.kd * d.kh * d.kw;
-    const bool m16 = d.dtype == RHO_BF16 && taps > 1 && d.sh == 1 && d.sw == 1 && !d.up_h && !d.up_w;
+    const bool m16 = d.dtype == RHO_BF16 && taps > 1 && taps % 3 == 0 && d.sh == 1 && d.sw == 1 && !d.up_h && !d.up_w;
     const int WSLOTS = (taps % 3 == 0) ? ((BM == 128 && RHO_GB_WIDE == 3 && m16 && taps % 9 == 0) ? 9 : 3) : 2;   // LDS weight-ring depth (matches the kernel's PIPE / RS)
     int np_cap = (int)((lds_cap - (size_t)WSLOTS * BM * PITCH) / PITCH);
     if (np_cap > 28 * 64) np_cap = 28 * 64;
@@ -1200,7 +1224,7 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
     // fused output statistics: only where a tile belongs to one sample and the whole output is channels-last
     int64_t tps = 0;
     if (d.split == d.cout && d.split > 0) {
-        if (d.kd == 3) tps = tiles;
+        if (d.kd == 3) tps = tiles * n_phase;            // phases: the launches of one output share the buffer, each its own tile range
         else if (taps == 1 && k.S_out % 256 == 0 && t.TW == 256) tps = k.S_out / 256;
     }
     if (stats_tiles) { *stats_tiles = tps; return 0; }
@@ -1208,6 +1232,7 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
     if (d.stats) {
         if (tps <= 0) return RHO_E_ARG;
         k.stats = d.stats; k.tps = (int)tps;
+        k.stats_off = phase_idx * (int)tiles;
     }
     k.gnb_x1 = nullptr;
     if (d.gnb_x1) {

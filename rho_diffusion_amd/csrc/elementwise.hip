@@ -509,6 +509,49 @@ extern "C" int rho_prep_conv_weight(const float* w, void* out, int dtype, int64_
     return 0;
 }
 
+// One sub-pixel phase of a conv behind a nearest x2 upsample: on a phased axis (3 taps -> 2) tap r of parity a sums the source
+// taps that land on the same source row: a = 0: {0}, {1, 2};  a = 1: {0, 1}, {2}.
+template <typename T>
+__global__ __launch_bounds__(256) void k_prep_w_phase(const float* __restrict__ w, T* __restrict__ out, int64_t cout, int64_t cin, int kd,
+                                                      int kh, int kw, int ph_h, int ph_w, int64_t coutp, int64_t cinp) {
+    const int kh2 = ph_h ? 2 : kh, kw2 = ph_w ? 2 : kw;
+    const int64_t taps2 = (int64_t)kd * kh2 * kw2, taps = (int64_t)kd * kh * kw;
+    const int64_t total = taps2 * coutp * cinp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t ci = i % cinp;
+        const int64_t co = (i / cinp) % coutp;
+        const int tap = (int)(i / (cinp * coutp));
+        const int c2 = tap % kw2, r2 = (tap / kw2) % kh2, dz = tap / (kw2 * kh2);
+        float v = 0.0f;
+        if (co < cout && ci < cin) {
+            // source tap range [lo, hi] per axis
+            int rlo = r2, rhi = r2, clo = c2, chi = c2;
+            if (ph_h) { if (ph_h == 1) { rlo = r2 ? 1 : 0; rhi = r2 ? 2 : 0; } else { rlo = r2 ? 2 : 0; rhi = r2 ? 2 : 1; } }
+            if (ph_w) { if (ph_w == 1) { clo = c2 ? 1 : 0; chi = c2 ? 2 : 0; } else { clo = c2 ? 2 : 0; chi = c2 ? 2 : 1; } }
+            const float* base = w + (co * cin + ci) * taps + (int64_t)dz * kh * kw;
+            for (int r = rlo; r <= rhi; ++r)
+                for (int c = clo; c <= chi; ++c) v += base[r * kw + c];
+        }
+        out[i] = cvt_out<T>(v);
+    }
+}
+
+extern "C" int rho_prep_conv_weight_phase(const float* w, void* out, int dtype, int64_t cout, int64_t cin, int kd, int kh, int kw, int ph_h,
+                                          int ph_w, int64_t coutp, int64_t cinp, void* stream) {
+    if (!w || !out || cout <= 0 || cin <= 0 || kd <= 0 || kh <= 0 || kw <= 0 || cinp < cin || coutp < cout) return RHO_E_ARG;
+    if (ph_h < 0 || ph_h > 2 || ph_w < 0 || ph_w > 2 || (!ph_h && !ph_w) || (ph_h && kh != 3) || (ph_w && kw != 3)) return RHO_E_ARG;
+    const int64_t total = (int64_t)kd * (ph_h ? 2 : kh) * (ph_w ? 2 : kw) * coutp * cinp;
+    dim3 grid(grid_for(total, 256)), block(256);
+    if (dtype == RHO_BF16)
+        hipLaunchKernelGGL(k_prep_w_phase<bf16_raw>, grid, block, 0, as_stream(stream), w, (bf16_raw*)out, cout, cin, kd, kh, kw, ph_h, ph_w, coutp, cinp);
+    else if (dtype == RHO_F32)
+        hipLaunchKernelGGL(k_prep_w_phase<float>, grid, block, 0, as_stream(stream), w, (float*)out, cout, cin, kd, kh, kw, ph_h, ph_w, coutp, cinp);
+    else
+        return RHO_E_ARG;
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
 // ================================================================================================ backward helpers
 
 // dgrad weights: out[tap'][ci][co'] = w[src(co')][ci][taps-1-tap']  (flipped taps, transposed channels), so that the

@@ -64,6 +64,7 @@ class _ConvW:
         self.b = torch.zeros(self.coutp, dtype=torch.float32, device=dev)
         self.wd: Optional[Tensor] = None     # dgrad weights, allocated with the first training plan
         self.zero_bias: Optional[Tensor] = None
+        self.wph: Optional[list] = None      # sub-pixel phase weights [(phase_hw, tensor)] of a conv behind a nearest x2 upsample
         self.refresh()
 
     def _geometry(self) -> None:          # subclasses re-interpret the parameter (see _StemAsGemm / _HeadAsGemm)
@@ -83,6 +84,13 @@ class _ConvW:
             self.zero_bias = torch.zeros(rows, dtype=torch.float32, device=self.w.device)
             self._refresh_dgrad()
 
+    def enable_phases(self, up_hw) -> None:
+        """The conv sits behind a nearest x2 upsample of the axes flagged in up_hw: one 2-tap weight set per output parity."""
+        if self.wph is None:
+            hs = (1, 2) if up_hw[0] else (0,)
+            ws = (1, 2) if up_hw[1] else (0,)
+            self.wph = [((a, b), ops.prep_conv_weight_phase(self._source(), self.dtype, (a, b))) for a in hs for b in ws]
+
     def _refresh_dgrad(self) -> None:
         w = self.weight.detach()
         w = w if w.is_contiguous() else w.contiguous()
@@ -98,6 +106,9 @@ class _ConvW:
         self.b[: b.numel()].copy_(b)
         if self.wd is not None:
             self._refresh_dgrad()
+        if self.wph is not None:
+            for ph, t in self.wph:
+                ops.prep_conv_weight_phase(self._source(), self.dtype, ph, out=t)
 
 
 class _StemAsGemm(_ConvW):
@@ -374,6 +385,8 @@ class _Plan:
         self.train = train
         self.materialize_act = os.environ.get("RHO_TRAIN_MATERIALIZE", "1") != "0"    # memory-for-time trade of training plans
         self.materialize_min_cout = int(os.environ.get("RHO_MATERIALIZE_MIN_COUT", "256"))
+        # Upsample + conv as sub-pixel phases (A/B switch)
+        self.phase_upsample = os.environ.get("RHO_PHASE_UPSAMPLE", "1") != "0"
         # backward: GroupNorm's reductions (sum dz, sum dz * x) in the epilogue of the dgrad launch that produces dz (A/B switch)
         # - from RHO_FUSE_GN_BWD channels up (0 = never): on the 64-channel layers the extra epilogue VALU work (one sigmoid per
         # element) costs the issue-bound narrow tiles more than the separate reduce pass it replaces
@@ -500,28 +513,43 @@ class _Plan:
                 self.ops.append(lambda s, a=ga: L.rho_gn_apply(*a, s))
                 self.info.append(dict(kind="gn_apply", flops=0.0, bytes=2.0 * esz * xact.numel()))
                 cx1, cx2, cpre = xact, None, None
-            d = ops.make_conv_desc(cx1, cx2, cw.w, cw.b, kernel=cw.kernel, cout=cout, split=split_, y=y, y2=y2,
-                                   stride_hw=stride_hw, up_hw=up_hw, pre_a=cpre["a"] if cpre else None,
-                                   pre_b=cpre["b"] if cpre else None, pre_silu=pre_silu if cpre else False, res=res, res_add=None)
-            if res_add_off is not None:
-                d.res_add = self.film.data_ptr() + 4 * res_add_off
-                d.res_add_stride = self.film.shape[1]
+            # A conv behind a nearest x2 upsample as one 2-tap launch per output parity on the SOURCE tensor (rho_conv_desc.ph_h):
+            # 12 / 27 of the multiply-adds in 3-D, same result up to the rounding of the summed weights.
+            phased = (self.phase_upsample and up_hw != (0, 0) and cpre is None and cx2 is None and split_ == cout and res is None
+                      and res_add_off is None and all(cw.kernel[1 + i] == 3 for i in range(2) if up_hw[i]))
+            if phased:
+                cw.enable_phases(up_hw)
+                descs = [ops.make_conv_desc(cx1, None, wt, cw.b, kernel=(cw.kernel[0], 2 if ph[0] else cw.kernel[1], 2 if ph[1] else cw.kernel[2]),
+                                            cout=cout, split=split_, y=y, y2=None, phase_hw=ph) for ph, wt in cw.wph]
+            else:
+                d = ops.make_conv_desc(cx1, cx2, cw.w, cw.b, kernel=cw.kernel, cout=cout, split=split_, y=y, y2=y2,
+                                       stride_hw=stride_hw, up_hw=up_hw, pre_a=cpre["a"] if cpre else None,
+                                       pre_b=cpre["b"] if cpre else None, pre_silu=pre_silu if cpre else False, res=res, res_add=None)
+                if res_add_off is not None:
+                    d.res_add = self.film.data_ptr() + 4 * res_add_off
+                    d.res_add_stride = self.film.shape[1]
+                descs = [d]
             if y is not None and split_ == cout and want_stats:
                 # GroupNorm statistics of the output ride along in the epilogue where the geometry allows it
-                tiles = int(L.rho_conv_stats_tiles(C.byref(d)))
+                tiles = int(L.rho_conv_stats_tiles(C.byref(descs[0])))       # (phases: all launches of this output together)
                 if tiles > 0:
                     sbuf = buf(N * tiles * 2 * cout, dtype=torch.float32)
-                    d.stats = sbuf.data_ptr()
+                    for d in descs:
+                        d.stats = sbuf.data_ptr()
                     self.tstats[y.data_ptr()] = (sbuf, tiles)
-            self.keep.append(d)
-            self.fwd_descs.append(d)
-            self.ops.append(lambda s, d=d: L.rho_conv_nd_fwd(C.byref(d), s))
             npos_out = N * Do * Ho * Wo
             npos_in = x1.numel() // x1.shape[-1]
-            self.info.append(dict(
-                kind="conv3" if cw.taps > 1 else "conv1", taps=cw.taps, cin=cw.cin, cout=cout, positions=npos_out,
-                flops=2.0 * npos_out * cout * cw.cin * cw.taps,                       # algorithmic (unpadded) MACs * 2
-                bytes=float(esz) * (npos_in * cw.cin + npos_out * cout * (2 if res is not None else 1) + cw.taps * cout * cw.cin)))
+            for d in descs:
+                self.keep.append(d)
+                self.fwd_descs.append(d)
+                self.ops.append(lambda s, d=d: L.rho_conv_nd_fwd(C.byref(d), s))
+                taps_run = d.kd * d.kh * d.kw
+                self.info.append(dict(
+                    kind="conv3" if cw.taps > 1 else "conv1", taps=cw.taps, cin=cw.cin, cout=cout, positions=npos_out // len(descs),
+                    flops=2.0 * npos_out * cout * cw.cin * cw.taps / len(descs),          # algorithmic (unpadded) MACs * 2
+                    executed_flops=2.0 * npos_out * cout * cw.cin * taps_run / len(descs),
+                    bytes=float(esz) * (npos_in * cw.cin + npos_out * cout * (2 if res is not None else 1) / len(descs)
+                                        + taps_run * cout * cw.cin)))
             self.nodes.append(dict(k="conv", cw=cw, x1=x1, x2=x2, y=y, y2=y2, stride_hw=stride_hw, up_hw=up_hw, pre=pre,
                                    pre_silu=pre_silu, res=res, res_add_off=res_add_off, stem=stem, out_dims=(N, Do, Ho, Wo),
                                    xact=xact))

@@ -154,6 +154,23 @@ def _run_layer(ops, case, check=True):
             got2 = y2.float().cpu().reshape(N, cout - split_, *ref.shape[2:])
             assert rel_l2(got2, ref[:, split_:]) < tol_f, f"fwd(y2) {name}"
 
+    if up and pre is None and not residual and split_ == cout:
+        # the engine's forward for Upsample + conv: one 2-tap launch per output parity on the source tensor (sub-pixel phases)
+        yp = torch.full((No, Do, Ho, Wo, cout), float("nan"), dtype=dtype, device=DEV)
+        pk = []
+        for a in ((1, 2) if up_hw[0] else (0,)):
+            for c in ((1, 2) if up_hw[1] else (0,)):
+                wph = ops.prep_conv_weight_phase(w.to(DEV), dtype, (a, c))
+                dp = ops.make_conv_desc(x1cl, None, wph, bp, kernel=(kernel[0], 2 if a else kernel[1], 2 if c else kernel[2]), cout=cout,
+                                        split=cout, y=yp, y2=None, phase_hw=(a, c))
+                pk.append((wph, dp))
+                variants.add(ops.conv_variant(dp))
+                if check:
+                    ops.conv_launch(dp)
+        if check:
+            gotp = from_cl(yp, dims)
+            assert not torch.isnan(gotp).any() and rel_l2(gotp, ref) < tol_f, f"fwd phases {name}: {rel_l2(gotp, ref):.3e}"
+
     # ---------------- data gradient (w.r.t. the activated input; the GroupNorm backward is a separate kernel)
     ck = 32 if dtype == BF16 else 16
     dyp = F.pad(dy, (0, 0) * dims + (0, (-cout) % ck)) if cout % ck else dy      # dY rows are as wide as the dgrad weights expect

@@ -455,3 +455,48 @@ def test_conv_bf16_every_tap_count_and_cout_tile(ops, kernel, shape, cin, cout):
     ops.conv_launch(d)
     ref = F.conv3d(x.float().permute(0, 4, 1, 2, 3), wt.to(torch.bfloat16).float(), b, padding=tuple(k // 2 for k in kernel)).permute(0, 2, 3, 4, 1)
     assert rel_l2(y.float(), ref) <= 4e-3
+
+
+PHASE_CASES = [((3, 3, 3), (2, 4, 8, 8), (1, 1), 64, 64), ((3, 3, 3), (1, 6, 8, 16), (1, 1), 128, 128), ((3, 3, 3), (2, 3, 5, 7), (1, 1), 32, 32),
+               ((1, 3, 3), (2, 1, 16, 16), (1, 1), 64, 128), ((1, 3, 3), (3, 1, 9, 11), (1, 1), 32, 64), ((1, 1, 3), (2, 1, 1, 128), (0, 1), 64, 64),
+               ((1, 1, 3), (2, 1, 1, 100), (0, 1), 32, 32)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("kernel,shape,up,cin,cout", PHASE_CASES, ids=[f"{'x'.join(map(str, c[0]))}-{c[3]}to{c[4]}" for c in PHASE_CASES])
+def test_upsample_conv_as_subpixel_phases(ops, dtype, kernel, shape, up, cin, cout):
+    """Upsample (nearest x2 on the inner axes, unet_v2.py:122-131) + conv as one 2-tap launch per output parity on the source
+    tensor (rho_conv_desc.ph_h / ph_w, rho_prep_conv_weight_phase) against torch: interpolate + convNd in fp32 on the same
+    operands - output and the fused GroupNorm statistics of the output (3-D).  f32: 2e-5 relative l2; bf16: 6e-3 (the phase
+    weights are sums of two / four bf16-rounded-later taps)."""
+    N, D, H, W = shape
+    x = rnd(det_normal((N, D, H, W, cin), "ph_x").to(DEV), dtype).to(dtype)
+    wt = det_normal((cout, cin) + tuple(kernel), "ph_w").to(DEV) * 0.05
+    b = det_normal((cout,), "ph_b").to(DEV)
+    Ho, Wo = H * (2 if up[0] else 1), W * (2 if up[1] else 1)
+    y = torch.full((N, D, Ho, Wo, cout), float("nan"), device=DEV, dtype=dtype)
+    descs, keep = [], []
+    for a in ((1, 2) if up[0] else (0,)):
+        for c in ((1, 2) if up[1] else (0,)):
+            wp = ops.prep_conv_weight_phase(wt, dtype, (a, c))
+            keep.append(wp)                                   # the descriptor holds a raw pointer
+            descs.append(ops.make_conv_desc(x, None, wp, b, kernel=(kernel[0], 2 if a else kernel[1], 2 if c else kernel[2]), cout=cout,
+                                            split=cout, y=y, y2=None, phase_hw=(a, c)))
+    tiles = ops.conv_stats_tiles(descs[0])
+    sbuf = None
+    if tiles > 0:
+        sbuf = torch.zeros(N, tiles, 2, cout, device=DEV)
+        for d in descs:
+            d.stats = sbuf.data_ptr()
+    for d in descs:
+        ops.conv_launch(d)
+    xu = x.float().permute(0, 4, 1, 2, 3)
+    xu = F.interpolate(xu, size=(D, Ho, Wo), mode="nearest")
+    ref = F.conv3d(xu, wt, b, padding=tuple(k // 2 for k in kernel)).permute(0, 2, 3, 4, 1)
+    assert not torch.isnan(y.float()).any()                                      # every output position written exactly by one phase
+    assert rel_l2(y.float(), ref) <= tol(dtype)
+    if sbuf is not None:
+        assert kernel[0] == 3
+        yy = y.float().reshape(N, -1, cout)
+        s1, s2 = sbuf[:, :, 0].sum(1), sbuf[:, :, 1].sum(1)
+        assert rel_l2(s1, yy.sum(1)) <= 1e-3 and rel_l2(s2, (yy * yy).sum(1)) <= 1e-3
