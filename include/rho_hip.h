@@ -201,6 +201,10 @@ typedef struct rho_conv_desc {
      * SOURCE tensor and writes every second output row / column: 12 instead of 27 taps in 3-D.  ph_h / ph_w: 0 = axis not
      * upsampled, 1 / 2 = parity 0 / 1.  y (and res, stats) describe the full-resolution output [N, D, 2H, 2W, cout]. */
     int32_t ph_h, ph_w;
+    /* data gradient of such a phase: the input (dY of the full-resolution output) is read at parity phd - 1 of the phased axis
+     * (d.h / d.w_ are the source-resolution extents, the tensor has twice as many rows / columns), 2-tap axis, taps start
+     * phd - 1 rows before the output position, dense output; the four launches accumulate into dX through `res`. */
+    int32_t phd_h, phd_w;
     /* --- GroupNorm BACKWARD reduction fused into a dgrad launch (the output is d act(a * x + b), x the forward input): with
      * gnb_x1 set, `stats` receives per tile and channel  row 0 = sum of dz,  row 1 = sum of dz * x  (dz = output * act'(a x + b),
      * the output as stored) instead of the output's own moments: what rho_gn_bwd_reduce reads two tensors to compute
@@ -222,9 +226,10 @@ int rho_conv_nd_fwd(const rho_conv_desc* desc, void* stream);
 
 /* Weights of one sub-pixel phase (see rho_conv_desc.ph_h): from the fp32 parameter [cout][cin][kd][kh][kw] (kh / kw = 3 on a
  * phased axis) to the launch layout [kd * kh' * kw' taps][coutp][cinp] with the two taps of a phased axis summed as described
- * there; ph_h / ph_w as in the descriptor. */
+ * there; ph_h / ph_w as in the descriptor.  dgrad = 1: the data-gradient layout instead, [taps][cinp rows = ceil32(cin)][coutp
+ * columns] with flipped taps and transposed channels (as rho_prep_conv_weight_dgrad), for a launch with phd_h / phd_w. */
 int rho_prep_conv_weight_phase(const float* w, void* out, int dtype, int64_t cout, int64_t cin, int kd, int kh, int kw, int ph_h,
-                               int ph_w, int64_t coutp, int64_t cinp, void* stream);
+                               int ph_w, int64_t coutp, int64_t cinp, int dgrad, void* stream);
 
 /* Number of output tiles per sample the launch of `desc` uses (the middle extent of desc->stats), or 0 when fused
  * statistics are not available for this geometry (channel-major outputs, tiles that straddle samples: 1-D / 2-D

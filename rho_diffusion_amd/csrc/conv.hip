@@ -63,6 +63,7 @@ struct ConvK {
     // output position; the launch writes output row oh * oy_mul + oy_add of a tensor with Ho_out x Wo_out rows per depth slice
     int pad_h, pad_w, oy_mul, oy_add, ox_mul, ox_add, Ho_out, Wo_out;
     int stats_off;        // first statistics tile of this launch within the tps tiles of a sample
+    int iy_mul, iy_add, ix_mul, ix_add;   // input row / column of virtual position g: g * mul + add (phd_*: one parity of a 2x tensor)
     // GroupNorm backward reduction fused into a dgrad launch (rho_conv_desc.gnb_*): stats <- per-tile sums of dz and dz * x
     const char* gnb_x1;
     const char* gnb_x2;
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                 if (p.zs_h) { ok = ok && ((gh & 1) == 0) && ((gh >> 1) < p.Hs); gh >>= 1; }
                 if (p.zs_w) { ok = ok && ((gw & 1) == 0) && ((gw >> 1) < p.Ws); gw >>= 1; }
                 if (ok) {
-                    pos = ((n * p.D + gd) * p.Hs + gh) * p.Ws + gw;
+                    pos = ((n * p.D + gd) * p.Hs + (gh * p.iy_mul + p.iy_add)) * p.Ws + (gw * p.ix_mul + p.ix_add);
                     if constexpr (KD != 3) smp = (int)((long long)pos / p.S_in);
                 } else {
                     pos = -1;
@@ -1130,15 +1131,19 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
     // sub-pixel phases: a 2-tap axis at the source resolution, stride 1, the output rows of one parity
     if (d.ph_h < 0 || d.ph_h > 2 || d.ph_w < 0 || d.ph_w > 2) return RHO_E_ARG;
     if ((d.ph_h && (d.kh != 2 || d.sh != 1 || d.up_h || d.zs_h)) || (d.ph_w && (d.kw != 2 || d.sw != 1 || d.up_w || d.zs_w))) return RHO_E_ARG;
-    if ((!d.ph_h && d.kh == 2) || (!d.ph_w && d.kw == 2)) return RHO_E_ARG;
+    if ((!d.ph_h && !d.phd_h && d.kh == 2) || (!d.ph_w && !d.phd_w && d.kw == 2)) return RHO_E_ARG;
     if ((d.ph_h || d.ph_w) && (d.split != d.cout || d.kd == 2)) return RHO_E_ARG;      // channels-last outputs only
+    if (d.phd_h < 0 || d.phd_h > 2 || d.phd_w < 0 || d.phd_w > 2) return RHO_E_ARG;
+    if ((d.phd_h && (d.kh != 2 || d.sh != 1 || d.up_h || d.zs_h || d.ph_h)) || (d.phd_w && (d.kw != 2 || d.sw != 1 || d.up_w || d.zs_w || d.ph_w)))
+        return RHO_E_ARG;
+    if ((d.phd_h || d.phd_w) && (d.kd == 2 || d.pre_a)) return RHO_E_ARG;
 
     // output extents per sample (padding k/2).  Zero-stuffed input (dgrad of a stride-2 conv): the
     // virtual input and the output both have the forward conv's input extent out_h / out_w.
     const int hv = d.zs_h ? d.out_h : d.h, wv = d.zs_w ? d.out_w : d.w_;   // virtual input extents
     // (phases: the launch's own output grid is the source grid; it lands on every second row / column of the real output)
-    const int ho = d.ph_h ? d.h : d.up_h ? d.h * 2 : (hv + 2 * (d.kh / 2) - d.kh) / d.sh + 1;
-    const int wo = d.ph_w ? d.w_ : d.up_w ? d.w_ * 2 : (wv + 2 * (d.kw / 2) - d.kw) / d.sw + 1;
+    const int ho = (d.ph_h || d.phd_h) ? d.h : d.up_h ? d.h * 2 : (hv + 2 * (d.kh / 2) - d.kh) / d.sh + 1;
+    const int wo = (d.ph_w || d.phd_w) ? d.w_ : d.up_w ? d.w_ * 2 : (wv + 2 * (d.kw / 2) - d.kw) / d.sw + 1;
     const int ho_out = d.ph_h ? 2 * ho : ho, wo_out = d.ph_w ? 2 * wo : wo;
     const int n_phase = (d.ph_h ? 2 : 1) * (d.ph_w ? 2 : 1);
     const int phase_idx = (d.ph_h ? d.ph_h - 1 : 0) * (d.ph_w ? 2 : 1) + (d.ph_w ? d.ph_w - 1 : 0);
@@ -1148,7 +1153,10 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
     //   1x1x1: everything is one long W axis;  1xkxk: depth*batch is the tile's depth axis.
     ConvK k{};
     int gridz = d.n;
-    k.pad_h = d.ph_h ? 2 - d.ph_h : d.kh / 2; k.pad_w = d.ph_w ? 2 - d.ph_w : d.kw / 2;
+    k.pad_h = d.ph_h ? 2 - d.ph_h : d.phd_h ? d.phd_h - 1 : d.kh / 2;
+    k.pad_w = d.ph_w ? 2 - d.ph_w : d.phd_w ? d.phd_w - 1 : d.kw / 2;
+    k.iy_mul = d.phd_h ? 2 : 1; k.iy_add = d.phd_h ? d.phd_h - 1 : 0;
+    k.ix_mul = d.phd_w ? 2 : 1; k.ix_add = d.phd_w ? d.phd_w - 1 : 0;
     k.oy_mul = d.ph_h ? 2 : 1; k.oy_add = d.ph_h ? d.ph_h - 1 : 0;
     k.ox_mul = d.ph_w ? 2 : 1; k.ox_add = d.ph_w ? d.ph_w - 1 : 0;
     if (d.kd == 1 && d.kh == 1 && d.kw == 1) {
@@ -1167,10 +1175,12 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
     k.Hs = k.H; k.Ws = k.W;
     if (d.zs_h) k.Hs = d.h;
     if (d.zs_w) k.Ws = d.w_;
+    if (d.phd_h) k.Hs = 2 * d.h;
+    if (d.phd_w) k.Ws = 2 * d.w_;
     k.zs_h = d.zs_h; k.zs_w = d.zs_w;
     k.y2_cl = d.y2_cl; k.res2 = (const char*)d.res2;
-    if ((long long)d.n * d.d * d.h * d.w_ >= (1LL << 31) || (long long)d.n * dout * ho_out * wo_out >= (1LL << 31)) return RHO_E_SHAPE;
-    k.S_in = (long long)d.d * d.h * d.w_;
+    if ((long long)d.n * d.d * d.h * d.w_ * (d.phd_h ? 2 : 1) * (d.phd_w ? 2 : 1) >= (1LL << 31) || (long long)d.n * dout * ho_out * wo_out >= (1LL << 31)) return RHO_E_SHAPE;
+    k.S_in = (long long)d.d * d.h * d.w_ * (d.phd_h ? 2 : 1) * (d.phd_w ? 2 : 1);
     k.S_out = (long long)dout * ho_out * wo_out;
     k.Ho_out = (d.kd == 1 && d.kh == 1 && d.kw == 1) ? 1 : ho_out;
     k.Wo_out = (d.kd == 1 && d.kh == 1 && d.kw == 1) ? k.Wo : wo_out;

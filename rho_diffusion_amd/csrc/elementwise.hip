@@ -511,41 +511,51 @@ extern "C" int rho_prep_conv_weight(const float* w, void* out, int dtype, int64_
 
 // One sub-pixel phase of a conv behind a nearest x2 upsample: on a phased axis (3 taps -> 2) tap r of parity a sums the source
 // taps that land on the same source row: a = 0: {0}, {1, 2};  a = 1: {0, 1}, {2}.
+__device__ __forceinline__ float phase_weight(const float* __restrict__ w, int64_t co, int64_t ci, int64_t cin, int tap2, int kd, int kh,
+                                              int kw, int ph_h, int ph_w) {
+    const int kh2 = ph_h ? 2 : kh, kw2 = ph_w ? 2 : kw;
+    const int c2 = tap2 % kw2, r2 = (tap2 / kw2) % kh2, dz = tap2 / (kw2 * kh2);
+    int rlo = r2, rhi = r2, clo = c2, chi = c2;          // source tap range per axis
+    if (ph_h) { if (ph_h == 1) { rlo = r2 ? 1 : 0; rhi = r2 ? 2 : 0; } else { rlo = r2 ? 2 : 0; rhi = r2 ? 2 : 1; } }
+    if (ph_w) { if (ph_w == 1) { clo = c2 ? 1 : 0; chi = c2 ? 2 : 0; } else { clo = c2 ? 2 : 0; chi = c2 ? 2 : 1; } }
+    const float* base = w + (co * cin + ci) * ((int64_t)kd * kh * kw) + (int64_t)dz * kh * kw;
+    float v = 0.0f;
+    for (int r = rlo; r <= rhi; ++r)
+        for (int c = clo; c <= chi; ++c) v += base[r * kw + c];
+    return v;
+}
+
+// dgrad = 0: forward layout [tap2][coutp][cinp];  dgrad = 1: data-gradient layout [tap'][rowsp = ceil32(cin)][colsp] with flipped
+// taps and transposed channels (as k_prep_w_dgrad), so the forward kernel run on the phase's dY computes its share of dX
 template <typename T>
 __global__ __launch_bounds__(256) void k_prep_w_phase(const float* __restrict__ w, T* __restrict__ out, int64_t cout, int64_t cin, int kd,
-                                                      int kh, int kw, int ph_h, int ph_w, int64_t coutp, int64_t cinp) {
-    const int kh2 = ph_h ? 2 : kh, kw2 = ph_w ? 2 : kw;
-    const int64_t taps2 = (int64_t)kd * kh2 * kw2, taps = (int64_t)kd * kh * kw;
-    const int64_t total = taps2 * coutp * cinp;
+                                                      int kh, int kw, int ph_h, int ph_w, int64_t d1, int64_t d2, int dgrad) {
+    const int64_t taps2 = (int64_t)kd * (ph_h ? 2 : kh) * (ph_w ? 2 : kw);
+    const int64_t total = taps2 * d1 * d2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t ci = i % cinp;
-        const int64_t co = (i / cinp) % coutp;
-        const int tap = (int)(i / (cinp * coutp));
-        const int c2 = tap % kw2, r2 = (tap / kw2) % kh2, dz = tap / (kw2 * kh2);
+        const int64_t i2 = i % d2, i1 = (i / d2) % d1;
+        const int tap = (int)(i / (d2 * d1));
         float v = 0.0f;
-        if (co < cout && ci < cin) {
-            // source tap range [lo, hi] per axis
-            int rlo = r2, rhi = r2, clo = c2, chi = c2;
-            if (ph_h) { if (ph_h == 1) { rlo = r2 ? 1 : 0; rhi = r2 ? 2 : 0; } else { rlo = r2 ? 2 : 0; rhi = r2 ? 2 : 1; } }
-            if (ph_w) { if (ph_w == 1) { clo = c2 ? 1 : 0; chi = c2 ? 2 : 0; } else { clo = c2 ? 2 : 0; chi = c2 ? 2 : 1; } }
-            const float* base = w + (co * cin + ci) * taps + (int64_t)dz * kh * kw;
-            for (int r = rlo; r <= rhi; ++r)
-                for (int c = clo; c <= chi; ++c) v += base[r * kw + c];
+        if (!dgrad) {                 // d1 = coutp, d2 = cinp
+            if (i1 < cout && i2 < cin) v = phase_weight(w, i1, i2, cin, tap, kd, kh, kw, ph_h, ph_w);
+        } else {                      // d1 = rows (input channels), d2 = columns (output channels)
+            if (i2 < cout && i1 < cin) v = phase_weight(w, i2, i1, cin, (int)(taps2 - 1 - tap), kd, kh, kw, ph_h, ph_w);
         }
         out[i] = cvt_out<T>(v);
     }
 }
 
 extern "C" int rho_prep_conv_weight_phase(const float* w, void* out, int dtype, int64_t cout, int64_t cin, int kd, int kh, int kw, int ph_h,
-                                          int ph_w, int64_t coutp, int64_t cinp, void* stream) {
+                                          int ph_w, int64_t coutp, int64_t cinp, int dgrad, void* stream) {
     if (!w || !out || cout <= 0 || cin <= 0 || kd <= 0 || kh <= 0 || kw <= 0 || cinp < cin || coutp < cout) return RHO_E_ARG;
     if (ph_h < 0 || ph_h > 2 || ph_w < 0 || ph_w > 2 || (!ph_h && !ph_w) || (ph_h && kh != 3) || (ph_w && kw != 3)) return RHO_E_ARG;
-    const int64_t total = (int64_t)kd * (ph_h ? 2 : kh) * (ph_w ? 2 : kw) * coutp * cinp;
+    const int64_t d1 = dgrad ? cinp : coutp, d2 = dgrad ? coutp : cinp;
+    const int64_t total = (int64_t)kd * (ph_h ? 2 : kh) * (ph_w ? 2 : kw) * d1 * d2;
     dim3 grid(grid_for(total, 256)), block(256);
     if (dtype == RHO_BF16)
-        hipLaunchKernelGGL(k_prep_w_phase<bf16_raw>, grid, block, 0, as_stream(stream), w, (bf16_raw*)out, cout, cin, kd, kh, kw, ph_h, ph_w, coutp, cinp);
+        hipLaunchKernelGGL(k_prep_w_phase<bf16_raw>, grid, block, 0, as_stream(stream), w, (bf16_raw*)out, cout, cin, kd, kh, kw, ph_h, ph_w, d1, d2, dgrad);
     else if (dtype == RHO_F32)
-        hipLaunchKernelGGL(k_prep_w_phase<float>, grid, block, 0, as_stream(stream), w, (float*)out, cout, cin, kd, kh, kw, ph_h, ph_w, coutp, cinp);
+        hipLaunchKernelGGL(k_prep_w_phase<float>, grid, block, 0, as_stream(stream), w, (float*)out, cout, cin, kd, kh, kw, ph_h, ph_w, d1, d2, dgrad);
     else
         return RHO_E_ARG;
     RHO_LAUNCH_CHECK();

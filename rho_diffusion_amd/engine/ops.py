@@ -217,19 +217,27 @@ def prep_conv_weight(w: Tensor, dtype: torch.dtype, coutp: Optional[int] = None,
     return out
 
 
-def prep_conv_weight_phase(w: Tensor, dtype: torch.dtype, phase_hw: Tuple[int, int], out: Optional[Tensor] = None) -> Tensor:
+def prep_conv_weight_phase(w: Tensor, dtype: torch.dtype, phase_hw: Tuple[int, int], out: Optional[Tensor] = None,
+                           dgrad: bool = False) -> Tensor:
     """Weights of one sub-pixel phase of a conv behind a nearest x2 upsample (rho_conv_desc.ph_h / ph_w): parameter
-    [Cout, Cin, *k] (k = 3 on a phased axis) -> [kd * kh' * kw', CoutP, CinP] with kh' / kw' = 2 on the phased axes."""
+    [Cout, Cin, *k] (k = 3 on a phased axis) -> [kd * kh' * kw', CoutP, CinP] with kh' / kw' = 2 on the phased axes; dgrad: the
+    data-gradient layout [taps, ceil32(Cin), ceilCK(Cout)] (flipped, transposed) for a launch with phd_h / phd_w."""
     _f32c(w, "w")
     cout, cin = w.shape[0], w.shape[1]
     k = [1] * (5 - w.dim()) + [int(v) for v in w.shape[2:]]
     k2 = (k[0], 2 if phase_hw[0] else k[1], 2 if phase_hw[1] else k[2])
     ck = elem_chunk(dtype)
-    cinp = ((cin + ck - 1) // ck) * ck
-    coutp = ((cout + 31) // 32) * 32
-    out = torch.empty(k2[0] * k2[1] * k2[2], coutp, cinp, dtype=dtype, device=w.device) if out is None else out
+    if dgrad:
+        cinp = ((cin + 31) // 32) * 32                   # rows of the dgrad weights = its output channels
+        coutp = ((cout + ck - 1) // ck) * ck             # columns = its input channels (chunked)
+        shape = (k2[0] * k2[1] * k2[2], cinp, coutp)
+    else:
+        cinp = ((cin + ck - 1) // ck) * ck
+        coutp = ((cout + 31) // 32) * 32
+        shape = (k2[0] * k2[1] * k2[2], coutp, cinp)
+    out = torch.empty(*shape, dtype=dtype, device=w.device) if out is None else out
     check(hip.lib().rho_prep_conv_weight_phase(ptr(w), ptr(out), dtype_code(dtype), cout, cin, k[0], k[1], k[2], int(phase_hw[0]),
-                                               int(phase_hw[1]), coutp, cinp, stream()), "rho_prep_conv_weight_phase")
+                                               int(phase_hw[1]), coutp, cinp, int(dgrad), stream()), "rho_prep_conv_weight_phase")
     return out
 
 
@@ -266,7 +274,8 @@ def make_conv_desc(x1: Tensor, x2: Optional[Tensor], w: Tensor, bias: Tensor, *,
                    cout: int, split: int, y: Optional[Tensor], y2: Optional[Tensor], stride_hw=(1, 1), up_hw=(0, 0),
                    pre_a: Optional[Tensor] = None, pre_b: Optional[Tensor] = None, pre_silu: bool = False,
                    res: Optional[Tensor] = None, res_add: Optional[Tensor] = None, res_add_stride: int = 0,
-                   y2_cl: bool = False, res2: Optional[Tensor] = None, zs_hw=(0, 0), out_hw=(0, 0), phase_hw=(0, 0)) -> ConvDesc:
+                   y2_cl: bool = False, res2: Optional[Tensor] = None, zs_hw=(0, 0), out_hw=(0, 0), phase_hw=(0, 0),
+                   phase_dgrad_hw=(0, 0)) -> ConvDesc:
     N, D, H, W, c1 = x1.shape
     d = ConvDesc()
     d.x1, d.x2 = ptr(x1), ptr(x2)
@@ -290,6 +299,11 @@ def make_conv_desc(x1: Tensor, x2: Optional[Tensor], w: Tensor, bias: Tensor, *,
     d.zs_h, d.zs_w = int(zs_hw[0]), int(zs_hw[1])
     d.out_h, d.out_w = int(out_hw[0]), int(out_hw[1])
     d.ph_h, d.ph_w = int(phase_hw[0]), int(phase_hw[1])
+    d.phd_h, d.phd_w = int(phase_dgrad_hw[0]), int(phase_dgrad_hw[1])
+    if d.phd_h:                                        # x1 is the full-resolution dY: the launch's grid is the source resolution
+        d.h = H // 2
+    if d.phd_w:
+        d.w_ = W // 2
     if w.shape[2] != d.c1 + d.c2:
         raise RhoHipError(f"conv: prepared weight has {w.shape[2]} input channels, inputs provide {d.c1 + d.c2}")
     return d

@@ -65,6 +65,7 @@ class _ConvW:
         self.wd: Optional[Tensor] = None     # dgrad weights, allocated with the first training plan
         self.zero_bias: Optional[Tensor] = None
         self.wph: Optional[list] = None      # sub-pixel phase weights [(phase_hw, tensor)] of a conv behind a nearest x2 upsample
+        self.wphd: Optional[list] = None     # ... and their data-gradient layouts (training plans)
         self.refresh()
 
     def _geometry(self) -> None:          # subclasses re-interpret the parameter (see _StemAsGemm / _HeadAsGemm)
@@ -84,12 +85,17 @@ class _ConvW:
             self.zero_bias = torch.zeros(rows, dtype=torch.float32, device=self.w.device)
             self._refresh_dgrad()
 
-    def enable_phases(self, up_hw) -> None:
-        """The conv sits behind a nearest x2 upsample of the axes flagged in up_hw: one 2-tap weight set per output parity."""
+    def enable_phases(self, up_hw, dgrad: bool = False) -> None:
+        """The conv sits behind a nearest x2 upsample of the axes flagged in up_hw: one 2-tap weight set per output parity
+        (and, for training plans, its data-gradient layout)."""
+        hs = (1, 2) if up_hw[0] else (0,)
+        ws = (1, 2) if up_hw[1] else (0,)
         if self.wph is None:
-            hs = (1, 2) if up_hw[0] else (0,)
-            ws = (1, 2) if up_hw[1] else (0,)
             self.wph = [((a, b), ops.prep_conv_weight_phase(self._source(), self.dtype, (a, b))) for a in hs for b in ws]
+        if dgrad and self.wphd is None:
+            self.wphd = [((a, b), ops.prep_conv_weight_phase(self._source(), self.dtype, (a, b), dgrad=True)) for a in hs for b in ws]
+            if self.zero_bias is None:
+                self.zero_bias = torch.zeros(((self.cin + 31) // 32) * 32, dtype=torch.float32, device=self.w.device)
 
     def _refresh_dgrad(self) -> None:
         w = self.weight.detach()
@@ -109,6 +115,9 @@ class _ConvW:
         if self.wph is not None:
             for ph, t in self.wph:
                 ops.prep_conv_weight_phase(self._source(), self.dtype, ph, out=t)
+        if self.wphd is not None:
+            for ph, t in self.wphd:
+                ops.prep_conv_weight_phase(self._source(), self.dtype, ph, out=t, dgrad=True)
 
 
 class _StemAsGemm(_ConvW):
@@ -387,6 +396,7 @@ class _Plan:
         self.materialize_min_cout = int(os.environ.get("RHO_MATERIALIZE_MIN_COUT", "256"))
         # Upsample + conv as sub-pixel phases (A/B switch)
         self.phase_upsample = os.environ.get("RHO_PHASE_UPSAMPLE", "1") != "0"
+        self.phase_upsample_bwd = os.environ.get("RHO_PHASE_UPSAMPLE_BWD", "1") != "0"
         # backward: GroupNorm's reductions (sum dz, sum dz * x) in the epilogue of the dgrad launch that produces dz (A/B switch)
         # - from RHO_FUSE_GN_BWD channels up (0 = never): on the 64-channel layers the extra epilogue VALU work (one sigmoid per
         # element) costs the issue-bound narrow tiles more than the separate reduce pass it replaces
@@ -518,7 +528,7 @@ class _Plan:
             phased = (self.phase_upsample and up_hw != (0, 0) and cpre is None and cx2 is None and split_ == cout and res is None
                       and res_add_off is None and all(cw.kernel[1 + i] == 3 for i in range(2) if up_hw[i]))
             if phased:
-                cw.enable_phases(up_hw)
+                cw.enable_phases(up_hw, dgrad=self.train)
                 descs = [ops.make_conv_desc(cx1, None, wt, cw.b, kernel=(cw.kernel[0], 2 if ph[0] else cw.kernel[1], 2 if ph[1] else cw.kernel[2]),
                                             cout=cout, split=split_, y=y, y2=None, phase_hw=ph) for ph, wt in cw.wph]
             else:
@@ -552,7 +562,7 @@ class _Plan:
                                         + taps_run * cout * cw.cin)))
             self.nodes.append(dict(k="conv", cw=cw, x1=x1, x2=x2, y=y, y2=y2, stride_hw=stride_hw, up_hw=up_hw, pre=pre,
                                    pre_silu=pre_silu, res=res, res_add_off=res_add_off, stem=stem, out_dims=(N, Do, Ho, Wo),
-                                   xact=xact))
+                                   xact=xact, phased=phased))
             return y, y2
 
         rs_hw = (1, 1) if dims >= 2 else (0, 1)      # axes a Down/Upsample touches: H and W (3-D: depth stays), 1-D: W only
@@ -856,7 +866,21 @@ class _Plan:
             if dyw != cw.wd.shape[2] or cw.wd.shape[1] != cin:
                 raise hip.RhoHipError("internal: dgrad weight shape does not match the gradient tensors")
             common = dict(kernel=cw.kernel, cout=cin)
-            if pre is not None or node["up_hw"] != (0, 0):
+            if node.get("phased") and pre is None and x2 is None and self.phase_upsample_bwd:
+                # Upsample + conv ran as sub-pixel phases: each phase's share of dX is a 2-tap conv of that parity of dY with the
+                # phase's flipped weights, accumulated in place - 12 / 27 of the multiply-adds, no full-resolution intermediate
+                g1, acc1 = gradbuf(x1)
+                for i, (ph, wt) in enumerate(cw.wphd):
+                    kern = (cw.kernel[0], 2 if ph[0] else cw.kernel[1], 2 if ph[1] else cw.kernel[2])
+                    d = ops.make_conv_desc(dY, None, wt, cw.zero_bias, kernel=kern, cout=cin, split=cin, y=g1, y2=None,
+                                           res=g1 if (acc1 or i > 0) else None, phase_dgrad_hw=ph)
+                    self.keep.append(d)
+                    self.fwd_descs.append(d)
+                    emit(lambda s, d=d: L.rho_conv_nd_fwd(C.byref(d), s), "dgrad",
+                         flops=2.0 * (dY.numel() // dyw) * cin * cw.cout * cw.taps / len(cw.wphd),
+                         nbytes=float(esz) * (dY.numel() / len(cw.wphd) + x1.numel() * (2 if (acc1 or i > 0) else 1)))
+                written.add(key(x1))
+            elif pre is not None or node["up_hw"] != (0, 0):
                 N, Do, Ho, Wo = node["out_dims"]
                 tshape = (N, Do, Ho, Wo, cin) if node["up_hw"] != (0, 0) else tuple(x1.shape[:4]) + (cin,)
                 dact = pool.get(tshape, dt)       # gradient of the activated / upsampled tensor

@@ -33,7 +33,7 @@ class ConvDesc(C.Structure):
         ("up_h", c_int32), ("up_w", c_int32), ("pre_silu", c_int32), ("res_add_stride", c_int32),
         ("y2_cl", c_int32), ("zs_h", c_int32), ("zs_w", c_int32), ("out_h", c_int32), ("out_w", c_int32),
         ("res2", c_void_p), ("stats", c_void_p),
-        ("ph_h", c_int32), ("ph_w", c_int32),
+        ("ph_h", c_int32), ("ph_w", c_int32), ("phd_h", c_int32), ("phd_w", c_int32),
         ("gnb_x1", c_void_p), ("gnb_x2", c_void_p), ("gnb_c1", c_int32), ("gnb_silu", c_int32), ("gnb_a", c_void_p), ("gnb_b", c_void_p),
     ]
 
@@ -59,7 +59,7 @@ SIGNATURES = {
     "rho_pack_input": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     "rho_prep_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "rho_prep_conv_weight_phase": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64,
-                                          c_void_p]),
+                                          c_int, c_void_p]),
     "rho_gn_nblk": (c_int, [c_int64]),
     "rho_gn_partial": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p]),
     "rho_gn_finalize": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,

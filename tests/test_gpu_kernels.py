@@ -490,9 +490,10 @@ def test_upsample_conv_as_subpixel_phases(ops, dtype, kernel, shape, up, cin, co
             d.stats = sbuf.data_ptr()
     for d in descs:
         ops.conv_launch(d)
-    xu = x.float().permute(0, 4, 1, 2, 3)
-    xu = F.interpolate(xu, size=(D, Ho, Wo), mode="nearest")
-    ref = F.conv3d(xu, wt, b, padding=tuple(k // 2 for k in kernel)).permute(0, 2, 3, 4, 1)
+    xr = x.float().permute(0, 4, 1, 2, 3).clone().requires_grad_(True)
+    xu = F.interpolate(xr, size=(D, Ho, Wo), mode="nearest")
+    refc = F.conv3d(xu, wt, b, padding=tuple(k // 2 for k in kernel))
+    ref = refc.detach().permute(0, 2, 3, 4, 1)
     assert not torch.isnan(y.float()).any()                                      # every output position written exactly by one phase
     assert rel_l2(y.float(), ref) <= tol(dtype)
     if sbuf is not None:
@@ -500,3 +501,23 @@ def test_upsample_conv_as_subpixel_phases(ops, dtype, kernel, shape, up, cin, co
         yy = y.float().reshape(N, -1, cout)
         s1, s2 = sbuf[:, :, 0].sum(1), sbuf[:, :, 1].sum(1)
         assert rel_l2(s1, yy.sum(1)) <= 1e-3 and rel_l2(s2, (yy * yy).sum(1)) <= 1e-3
+    # data gradient: each phase's share is a 2-tap conv of that parity of dY with the phase's flipped weights (phd_h / phd_w),
+    # accumulated in place - against autograd through interpolate + conv
+    ck = 32 if dtype == torch.bfloat16 else 16
+    dyw = ((cout + ck - 1) // ck) * ck
+    dy = torch.zeros(N, D, Ho, Wo, dyw, device=DEV, dtype=dtype)
+    dy[..., :cout] = rnd(det_normal((N, D, Ho, Wo, cout), "ph_dy").to(DEV), dtype).to(dtype)
+    refc.backward(dy[..., :cout].float().permute(0, 4, 1, 2, 3))
+    gx = xr.grad.permute(0, 2, 3, 4, 1)
+    dx = torch.full((N, D, H, W, cin), float("nan"), device=DEV, dtype=dtype)
+    zb = torch.zeros(((cin + 31) // 32) * 32, device=DEV)
+    i = 0
+    for a in ((1, 2) if up[0] else (0,)):
+        for c in ((1, 2) if up[1] else (0,)):
+            wd = ops.prep_conv_weight_phase(wt, dtype, (a, c), dgrad=True)
+            keep.append(wd)
+            dd = ops.make_conv_desc(dy, None, wd, zb, kernel=(kernel[0], 2 if a else kernel[1], 2 if c else kernel[2]), cout=cin, split=cin,
+                                    y=dx, y2=None, res=dx if i > 0 else None, phase_dgrad_hw=(a, c))
+            ops.conv_launch(dd)
+            i += 1
+    assert rel_l2(dx.float(), gx) <= (1.5e-2 if dtype == torch.bfloat16 else 5e-5)
