@@ -289,6 +289,12 @@ int rho_conv_wgrad_variant(const rho_conv_desc* desc, int64_t dy_width, char* bu
 int rho_wgrad_finalize(const float* dw, float* grad, int64_t cout, int64_t cin, int64_t taps, int64_t coutp,
                        int64_t cin_buf, const int32_t* row_src, int accumulate, void* stream);
 
+/* ... of one sub-pixel phase (rho_conv_desc.ph_h / ph_w; dw = [kd * kh' * kw' taps][coutp][cin_buf] from rho_conv_nd_wgrad on the
+ * phase's forward descriptor): every original tap of the [cout][cin][kd * kh * kw] parameter gradient takes the phase tap its row /
+ * column was summed into; call once per phase with accumulate = 1 (the phases add up). */
+int rho_wgrad_finalize_phase(const float* dw, float* grad, int64_t cout, int64_t cin, int kd, int kh, int kw, int ph_h, int ph_w,
+                             int64_t coutp, int64_t cin_buf, int accumulate, void* stream);
+
 /* Weights for the data gradient: out[tap'][ci][co'] = w[src(co')][ci][taps-1-tap'] so that rho_conv_nd_fwd
  * applied to dY yields dX.  rows padded to rowsp, cols to colsp. */
 int rho_prep_conv_weight_dgrad(const float* w, void* out, int dtype, int64_t cout, int64_t cin, int64_t taps,

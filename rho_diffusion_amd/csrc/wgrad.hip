@@ -43,6 +43,9 @@ struct WgradK {
     int lgTW, lgTH;
     int tiles_d, tiles_h, tiles_w, n_batch;
     int tiles_total, tiles_per_block;
+    // sub-pixel phase of a conv behind a nearest x2 upsample (rho_conv_desc.ph_h / ph_w): taps start pad_h / pad_w rows before
+    // the output position; dY row of output row oh: oh * oy_mul + oy_add in a tensor of Ho_out x Wo_out rows per depth slice
+    int pad_h, pad_w, oy_mul, oy_add, ox_mul, ox_add, Ho_out, Wo_out;
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
         const int row = (tid >> 3) + 32 * i;
         const int pw = row & (p.TW - 1), ph = (row >> p.lgTW) & (p.TH - 1), pd = row >> (p.lgTW + p.lgTH);
         ddec[i] = (pd << 20) | (ph << 10) | pw;
-        drel[i] = (pd * p.Ho + ph) * p.Wo + pw;
+        drel[i] = (pd * p.Ho_out + ph * p.oy_mul) * p.Wo_out + pw * p.ox_mul;
     }
 
     // taps of this wave
@@ -220,9 +223,9 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
         const int n = t / p.tiles_d;
         n_cur = n;
         const int od0 = td_i * p.TD, oh0 = th_i * p.TH, ow0 = tw_i * p.TW;
-        gd_base = od0 - (KD / 2); gh_base = oh0 * p.sh - (KH / 2); gw_base = ow0 * p.sw - (KW / 2);
+        gd_base = od0 - (KD / 2); gh_base = oh0 * p.sh - p.pad_h; gw_base = ow0 * p.sw - p.pad_w;
         base = ((n * p.D + gd_base) * p.H + gh_base) * p.W + gw_base;
-        dbase = ((n * p.Do + od0) * p.Ho + oh0) * p.Wo + ow0;
+        dbase = ((n * p.Do + od0) * p.Ho_out + oh0 * p.oy_mul + p.oy_add) * p.Wo_out + ow0 * p.ox_mul + p.ox_add;
         full = od0 + p.TD <= p.Do && oh0 + p.TH <= p.Ho && ow0 + p.TW <= p.Wo;
     };
     auto issue_x = [&](auto LO, auto HI) {
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
             for (int i = 0; i < 8; ++i)
                 dv[i] = *reinterpret_cast<const uint4*>(dsrc + (size_t)(dch_ok ? dbase + drel[i] : 0) * p.dyw * sizeof(T));
         } else {
-            const int od_lim = p.Do - (gd_base + KD / 2), oh_lim = p.Ho - (gh_base + KH / 2) / p.sh, ow_lim = p.Wo - (gw_base + KW / 2) / p.sw;
+            const int od_lim = p.Do - (gd_base + KD / 2), oh_lim = p.Ho - (gh_base + p.pad_h) / p.sh, ow_lim = p.Wo - (gw_base + p.pad_w) / p.sw;
             dok = 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -326,8 +329,8 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
         auto decode2 = [&](int tl) {                                       // wave-uniform part (scalar unit)
             decode(tl);
             od_lim = p.Do - (gd_base + KD / 2);
-            oh_lim = p.Ho - (gh_base + KH / 2) / p.sh;
-            ow_lim = p.Wo - (gw_base + KW / 2) / p.sw;
+            oh_lim = p.Ho - (gh_base + p.pad_h) / p.sh;
+            ow_lim = p.Wo - (gw_base + p.pad_w) / p.sw;
         };
         auto addr_slot = [&](auto SL) {                                    // global source of slot SL of the tile last decoded
             constexpr int sl = decltype(SL)::value;
@@ -689,6 +692,10 @@ int launch_wgrad(const WgradK& k, int maxp, dim3 grid, size_t lds, hipStream_t s
         return e == hipSuccess ? 0 : (int)e;
     };
     const bool pre = k.pre_a != nullptr;
+    if constexpr (KH == 2 || KW == 2) {      // sub-pixel phases: stride 1, small halo, no prologue (checked by the caller)
+        if (maxp > 10 || pre) return RHO_E_SHAPE;
+        return go(k_wgrad<T, KD, KH, KW, 10, false>);
+    }
     if (maxp <= 10) return pre ? go(k_wgrad<T, KD, KH, KW, 10, true>) : go(k_wgrad<T, KD, KH, KW, 10, false>);
     return pre ? go(k_wgrad<T, KD, KH, KW, 28, true>) : go(k_wgrad<T, KD, KH, KW, 28, false>);
 }
@@ -699,6 +706,10 @@ int launch_wgrad_taps(const rho_conv_desc& d, const WgradK& k, int maxp, dim3 gr
     if (d.kd == 1 && d.kh == 3 && d.kw == 3) return launch_wgrad<T, 1, 3, 3>(k, maxp, grid, lds, st);
     if (d.kd == 1 && d.kh == 1 && d.kw == 3) return launch_wgrad<T, 1, 1, 3>(k, maxp, grid, lds, st);
     if (d.kd == 1 && d.kh == 1 && d.kw == 1) return launch_wgrad<T, 1, 1, 1>(k, maxp, grid, lds, st);
+    // sub-pixel phases of a conv behind a nearest x2 upsample
+    if (d.kd == 3 && d.kh == 2 && d.kw == 2) return launch_wgrad<T, 3, 2, 2>(k, maxp, grid, lds, st);
+    if (d.kd == 1 && d.kh == 2 && d.kw == 2) return launch_wgrad<T, 1, 2, 2>(k, maxp, grid, lds, st);
+    if (d.kd == 1 && d.kh == 1 && d.kw == 2) return launch_wgrad<T, 1, 1, 2>(k, maxp, grid, lds, st);
     return RHO_E_ARG;
 }
 
@@ -745,9 +756,17 @@ static int wgrad_impl(const rho_conv_desc* dp, const void* dy, int64_t dy_width,
     if ((d.sh != 1 && d.sh != 2) || (d.sw != 1 && d.sw != 2)) return RHO_E_ARG;
     if (d.pre_a && !d.pre_b) return RHO_E_ARG;
 
-    const int ho = (d.h + 2 * (d.kh / 2) - d.kh) / d.sh + 1;
-    const int wo = (d.w_ + 2 * (d.kw / 2) - d.kw) / d.sw + 1;
+    if (d.phd_h || d.phd_w || d.ph_h < 0 || d.ph_h > 2 || d.ph_w < 0 || d.ph_w > 2) return RHO_E_ARG;
+    if ((d.ph_h && (d.kh != 2 || d.sh != 1)) || (d.ph_w && (d.kw != 2 || d.sw != 1)) || (!d.ph_h && d.kh == 2) || (!d.ph_w && d.kw == 2) ||
+        ((d.ph_h || d.ph_w) && (d.pre_a || d.kd == 2)))
+        return RHO_E_ARG;
+    // (phases: the launch's output grid is the source grid; dY is the full-resolution gradient, read at one parity)
+    const int ho = d.ph_h ? d.h : (d.h + 2 * (d.kh / 2) - d.kh) / d.sh + 1;
+    const int wo = d.ph_w ? d.w_ : (d.w_ + 2 * (d.kw / 2) - d.kw) / d.sw + 1;
     WgradK k{};
+    k.pad_h = d.ph_h ? 2 - d.ph_h : d.kh / 2; k.pad_w = d.ph_w ? 2 - d.ph_w : d.kw / 2;
+    k.oy_mul = d.ph_h ? 2 : 1; k.oy_add = d.ph_h ? d.ph_h - 1 : 0;
+    k.ox_mul = d.ph_w ? 2 : 1; k.ox_add = d.ph_w ? d.ph_w - 1 : 0;
     int nb = d.n;
     if (d.kd == 1 && d.kh == 1 && d.kw == 1) {
         if (d.sh != 1 || d.sw != 1) return RHO_E_ARG;
@@ -762,8 +781,9 @@ static int wgrad_impl(const rho_conv_desc* dp, const void* dy, int64_t dy_width,
         k.D = d.d; k.H = d.h; k.W = d.w_;
         k.Do = d.d; k.Ho = ho; k.Wo = wo;
     }
-    if ((long long)d.n * d.d * d.h * d.w_ >= (1LL << 31)) return RHO_E_SHAPE;
+    if ((long long)d.n * d.d * d.h * d.w_ * k.oy_mul * k.ox_mul >= (1LL << 31)) return RHO_E_SHAPE;
     k.S_in = (long long)d.d * d.h * d.w_;
+    k.Ho_out = k.Ho * k.oy_mul; k.Wo_out = k.Wo * k.ox_mul;
 
     if (d.dtype == RHO_BF16 && d.kd == 1 && d.kh == 1 && d.kw == 1 && !d.pre_a) {
         // 1x1x1 without prologue: the GEMM-shaped kernel
@@ -860,6 +880,40 @@ extern "C" int rho_wgrad_finalize(const float* dw, float* grad, int64_t cout, in
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(k_wgrad_finalize, dim3((unsigned)g), dim3(256), 0, as_stream(stream), dw, grad, cout, cin, taps, coutp, cin_buf,
                        row_src, accumulate);
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
+// Weight gradient of one sub-pixel phase (buffer [kd * kh' * kw' taps][coutp][cin_buf], kh' / kw' = 2 on the phased axes) into the
+// parameter gradient [cout][cin][kd * kh * kw]: original tap (kz, ky, kx) of parity a received the phase tap its row was summed
+// into (a = 0: {0}, {1, 2};  a = 1: {0, 1}, {2}), so its gradient is that phase tap's - summed over the phases by accumulate = 1.
+__global__ __launch_bounds__(256) void k_wgrad_finalize_phase(const float* __restrict__ dw, float* __restrict__ grad, int64_t cout,
+                                                              int64_t cin, int kd, int kh, int kw, int ph_h, int ph_w, int64_t coutp,
+                                                              int64_t cinb, int accumulate) {
+    const int64_t taps = (int64_t)kd * kh * kw;
+    const int kh2 = ph_h ? 2 : kh, kw2 = ph_w ? 2 : kw;
+    const int64_t total = cout * cin * taps;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % taps);
+        const int64_t ci = (i / taps) % cin;
+        const int64_t r = i / (taps * cin);
+        const int kx = tap % kw, ky = (tap / kw) % kh, kz = tap / (kw * kh);
+        const int r2 = ph_h == 0 ? ky : ph_h == 1 ? (ky == 0 ? 0 : 1) : (ky == 2 ? 1 : 0);
+        const int c2 = ph_w == 0 ? kx : ph_w == 1 ? (kx == 0 ? 0 : 1) : (kx == 2 ? 1 : 0);
+        const float v = dw[((int64_t)((kz * kh2 + r2) * kw2 + c2) * coutp + r) * cinb + ci];
+        float* g = grad + i;
+        *g = accumulate ? *g + v : v;
+    }
+}
+
+extern "C" int rho_wgrad_finalize_phase(const float* dw, float* grad, int64_t cout, int64_t cin, int kd, int kh, int kw, int ph_h, int ph_w,
+                                        int64_t coutp, int64_t cin_buf, int accumulate, void* stream) {
+    if (!dw || !grad || cout <= 0 || cin <= 0 || kd <= 0 || kh <= 0 || kw <= 0 || coutp < cout || cin_buf < cin) return RHO_E_ARG;
+    if (ph_h < 0 || ph_h > 2 || ph_w < 0 || ph_w > 2 || (!ph_h && !ph_w) || (ph_h && kh != 3) || (ph_w && kw != 3)) return RHO_E_ARG;
+    int64_t g = (cout * cin * kd * kh * kw + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_wgrad_finalize_phase, dim3((unsigned)g), dim3(256), 0, as_stream(stream), dw, grad, cout, cin, kd, kh, kw, ph_h, ph_w,
+                       coutp, cin_buf, accumulate);
     RHO_LAUNCH_CHECK();
     return 0;
 }

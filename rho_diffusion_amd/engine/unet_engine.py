@@ -769,6 +769,30 @@ class _Plan:
                 a = (ptr(dY), dtc, N, S, dyw, ptr(part), dst, film_stride, 0, None, 0)
                 emit(lambda s, a=a: L.rho_chan_sum(*a, s), "chan_sum", nbytes=float(esz) * N * S * dyw)
             pool.put(part)
+            if node.get("phased") and node["pre"] is None and node["x2"] is None and self.phase_upsample_bwd:
+                # Upsample + conv ran as sub-pixel phases: per phase a 2-tap weight gradient on the SOURCE tensor against that parity
+                # of dY (12 / 27 of the multiply-adds, no upsampled copy), routed back to the 3-tap parameter gradient
+                x1 = node["x1"]
+                cbv = c_tmp[:max(dyw, cw.coutp)]
+                emit(lambda s, t2=cbv: (t2.zero_(), 0)[1], "memset", nbytes=4.0 * cbv.numel())
+                for ph, wt in cw.wph:
+                    kern = (cw.kernel[0], 2 if ph[0] else cw.kernel[1], 2 if ph[1] else cw.kernel[2])
+                    d = ops.make_conv_desc(x1, None, wt, cw.b, kernel=kern, cout=cw.cout, split=cw.cout, y=dY, y2=None, phase_hw=ph)
+                    self.keep.append(d)
+                    self.wgrad_descs.append((d, dyw))
+                    nwp = kern[0] * kern[1] * kern[2] * cw.coutp * cw.cinp
+                    dwv = dwbuf[:nwp]
+                    emit(lambda s, t=dwv: (t.zero_(), 0)[1], "memset", nbytes=4.0 * nwp)
+                    emit(lambda s, d=d, dy=ptr(dY), w_=dyw: L.rho_conv_nd_wgrad(C.byref(d), dy, w_, ptr(dwbuf), ptr(c_tmp), s), "wgrad",
+                         flops=2.0 * N * S * cw.cout * cw.cin * cw.taps / len(cw.wph),
+                         nbytes=float(esz) * (x1.numel() + dY.numel() / len(cw.wph)),
+                         cin=cw.cin, cout=cw.cout, taps=cw.taps, positions=N * S // len(cw.wph))
+                    emit(lambda s, cw=cw, ph=ph: L.rho_wgrad_finalize_phase(ptr(dwbuf), pgrad(cw.weight), cw.cout, cw.cin, cw.kernel[0],
+                                                                           cw.kernel[1], cw.kernel[2], ph[0], ph[1], cw.coutp, cw.cinp, 1, s),
+                         "wgrad_finalize", nbytes=8.0 * nwp)
+                emit(lambda s, cw=cw, rs=rs, w_=dyw: L.rho_wgrad_finalize(ptr(c_tmp), pgrad(cw.bias_param), cw.cout, 1, 1, w_, 1, rs, 1, s),
+                     "bias_grad")
+                return
             # weight gradient (forward descriptor; upsampled input materialised)
             x1 = node["x1"]
             tmp_up = None

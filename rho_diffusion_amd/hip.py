@@ -77,6 +77,8 @@ SIGNATURES = {
     # ---- backward
     "rho_conv_nd_wgrad": (c_int, [C.POINTER(ConvDesc), c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "rho_wgrad_finalize": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int, c_void_p]),
+    "rho_wgrad_finalize_phase": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int,
+                                        c_void_p]),
     "rho_prep_conv_weight_dgrad": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "rho_gn_bwd_reduce": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p,
                                   c_void_p, c_int, c_void_p, c_void_p]),

@@ -170,6 +170,32 @@ def _run_layer(ops, case, check=True):
         if check:
             gotp = from_cl(yp, dims)
             assert not torch.isnan(gotp).any() and rel_l2(gotp, ref) < tol_f, f"fwd phases {name}: {rel_l2(gotp, ref):.3e}"
+        # ... its data gradient (one 2-tap launch per parity of dY, accumulated in place) and weight gradient (per phase, routed
+        # back to the 3-tap parameter gradient), as the training plans run them
+        ckp = 32 if dtype == BF16 else 16
+        dyp_ = F.pad(dy, (0, 0) * dims + (0, (-cout) % ckp)) if cout % ckp else dy
+        dycl_ = to_cl(dyp_, dtype)
+        dxp = torch.full(tuple(x1cl.shape), float("nan"), dtype=dtype, device=DEV)
+        zbp = torch.zeros(((cin + 31) // 32) * 32, device=DEV)
+        gradp = torch.zeros(tuple(w.shape), device=DEV)
+        from rho_diffusion_amd import hip as _hip
+        for i, (wph, dp) in enumerate(pk):
+            ph = (dp.ph_h, dp.ph_w)
+            wdp = ops.prep_conv_weight_phase(w.to(DEV), dtype, ph, dgrad=True)
+            ddp = ops.make_conv_desc(dycl_, None, wdp, zbp, kernel=(dp.kd, dp.kh, dp.kw), cout=cin, split=cin, y=dxp, y2=None,
+                                     res=dxp if i > 0 else None, phase_dgrad_hw=ph)
+            pk[i] = (wph, dp, wdp, ddp)
+            variants.add(ops.conv_variant(ddp))
+            variants.add(ops.conv_wgrad_variant(dp, dycl_.shape[-1]))
+            if check:
+                ops.conv_launch(ddp)
+                dwb = torch.zeros(tuple(wph.shape), dtype=torch.float32, device=DEV)
+                ops.conv_wgrad(dp, dycl_, dwb, None)
+                _hip.check(_hip.lib().rho_wgrad_finalize_phase(dwb.data_ptr(), gradp.data_ptr(), cout, cin, kernel[0], kernel[1], kernel[2],
+                                                              ph[0], ph[1], wph.shape[1], wph.shape[2], 1, _hip.stream()), "finalize_phase")
+        if check:
+            assert rel_l2(from_cl(dxp, dims), gx) < tol_b, f"dgrad phases {name}"
+            assert rel_l2(gradp, gw) < tol_b, f"wgrad phases {name}"
 
     # ---------------- data gradient (w.r.t. the activated input; the GroupNorm backward is a separate kernel)
     ck = 32 if dtype == BF16 else 16

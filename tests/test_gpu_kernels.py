@@ -521,3 +521,22 @@ def test_upsample_conv_as_subpixel_phases(ops, dtype, kernel, shape, up, cin, co
             ops.conv_launch(dd)
             i += 1
     assert rel_l2(dx.float(), gx) <= (1.5e-2 if dtype == torch.bfloat16 else 5e-5)
+    # weight gradient: per phase a 2-tap weight gradient on the source tensor against that parity of dY, routed to the 3-tap
+    # parameter gradient (rho_wgrad_finalize_phase); bias gradient = the channel sums of dY over all parities
+    wtr = wt.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    F.conv3d(F.interpolate(x.float().permute(0, 4, 1, 2, 3), size=(D, Ho, Wo), mode="nearest"), wtr, br,
+             padding=tuple(k // 2 for k in kernel)).backward(dy[..., :cout].float().permute(0, 4, 1, 2, 3))
+    grad = torch.zeros_like(wt)
+    coutp = ((cout + 31) // 32) * 32
+    dbias = torch.zeros(max(coutp, dyw), device=DEV)
+    from rho_diffusion_amd import hip
+    for dsc, wp in zip(descs, keep):
+        dsc.stats = None
+        dwb = torch.zeros(tuple(wp.shape), dtype=torch.float32, device=DEV)
+        ops.conv_wgrad(dsc, dy, dwb, dbias)
+        hip.check(hip.lib().rho_wgrad_finalize_phase(dwb.data_ptr(), grad.data_ptr(), cout, cin, kernel[0], kernel[1], kernel[2], dsc.ph_h,
+                                                     dsc.ph_w, wp.shape[1], wp.shape[2], 1, hip.stream()), "rho_wgrad_finalize_phase")
+    tb = 1.5e-2 if dtype == torch.bfloat16 else 5e-5
+    assert rel_l2(grad, wtr.grad) <= tb
+    assert rel_l2(dbias[:cout], br.grad) <= 1e-4
