@@ -397,6 +397,7 @@ class _Plan:
         # Upsample + conv as sub-pixel phases (A/B switch)
         self.phase_upsample = os.environ.get("RHO_PHASE_UPSAMPLE", "1") != "0"
         self.phase_upsample_bwd = os.environ.get("RHO_PHASE_UPSAMPLE_BWD", "1") != "0"
+        self.phase_min_wgs = int(os.environ.get("RHO_PHASE_MIN_WGS", "256"))
         # backward: GroupNorm's reductions (sum dz, sum dz * x) in the epilogue of the dgrad launch that produces dz (A/B switch)
         # - from RHO_FUSE_GN_BWD channels up (0 = never): on the 64-channel layers the extra epilogue VALU work (one sigmoid per
         # element) costs the issue-bound narrow tiles more than the separate reduce pass it replaces
@@ -525,8 +526,13 @@ class _Plan:
                 cx1, cx2, cpre = xact, None, None
             # A conv behind a nearest x2 upsample as one 2-tap launch per output parity on the SOURCE tensor (rho_conv_desc.ph_h):
             # 12 / 27 of the multiply-adds in 3-D, same result up to the rounding of the summed weights.
+            # (only where each phase launch still fills the chip: on the small 2-D grids of c1 four launches of a few workgroups
+            #  each are slower than one - 20.2 -> 21.5 ms per step there)
+            n_ph = (2 if up_hw[0] else 1) * (2 if up_hw[1] else 1)
+            wgs_per_phase = (N * Do * Ho * Wo // n_ph // 256) * max(1, cw.coutp // 128)
             phased = (self.phase_upsample and up_hw != (0, 0) and cpre is None and cx2 is None and split_ == cout and res is None
-                      and res_add_off is None and all(cw.kernel[1 + i] == 3 for i in range(2) if up_hw[i]))
+                      and res_add_off is None and all(cw.kernel[1 + i] == 3 for i in range(2) if up_hw[i])
+                      and wgs_per_phase >= self.phase_min_wgs)
             if phased:
                 cw.enable_phases(up_hw, dgrad=self.train)
                 descs = [ops.make_conv_desc(cx1, None, wt, cw.b, kernel=(cw.kernel[0], 2 if ph[0] else cw.kernel[1], 2 if ph[1] else cw.kernel[2]),

@@ -56,6 +56,21 @@ def test_unet_forward_vs_reference_golden(case, dtype):
     assert err < (F32_TOL if dtype == torch.float32 else BF16_TOL), f"{case} rel_l2={err:.3e}"
 
 
+@pytest.mark.parametrize("case", list(UNET_CASES.keys()))
+def test_unet_forward_with_fused_upsample_launch(case, monkeypatch):
+    """The launch small production grids keep for Upsample + conv (nearest x2 folded into the loader, one 27-tap launch) instead of
+    the sub-pixel phases the suite otherwise forces on (conftest.py): same goldens, forward and training step's loss."""
+    monkeypatch.setenv("RHO_PHASE_UPSAMPLE", "0")
+    g = load_golden("g4_unet.npz")
+    model = _build(case, torch.float32)
+    model.load_state_dict(det_state_dict(golden_template(g, case), case))
+    model = model.to(DEV)
+    cfg, x, t, y = case_inputs(case)
+    with torch.no_grad():
+        pred = model(x.to(DEV), t.to(DEV), y.to(DEV) if y is not None else None)
+    assert rel_l2(pred, torch.from_numpy(g[f"{case}/pred"])) < F32_TOL
+
+
 def test_reference_smoke_shapes():
     """The reference's own smoke test (tests/models/test_unet.py:36-56): rand(8,3,24,16), t = arange(8)."""
     from rho_diffusion_amd.models import UNet
