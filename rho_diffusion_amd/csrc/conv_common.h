@@ -35,19 +35,29 @@ __device__ __forceinline__ uint4 apply_pre<bf16_raw>(uint4 v, const float* __res
     const f32x2_t bv[4] = {{b0.x, b0.y}, {b0.z, b0.w}, {b1.x, b1.y}, {b1.z, b1.w}};
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
     uint32_t r[4];
+    // one wave-uniform branch around the whole piece: with the test inside the element loop the compiler speculates the sigmoid
+    // and selects (8 v_cndmask per piece on top of it)
+    if (silu) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const f32x2_t x = {__uint_as_float(w[j] << 16), __uint_as_float(w[j] & 0xFFFF0000u)};
-        f32x2_t y = __builtin_elementwise_fma(av[j], x, bv[j]);
-        if (silu) {
+        for (int j = 0; j < 4; ++j) {
+            const f32x2_t x = {__uint_as_float(w[j] << 16), __uint_as_float(w[j] & 0xFFFF0000u)};
+            f32x2_t y = __builtin_elementwise_fma(av[j], x, bv[j]);
             const f32x2_t t = y * -1.4426950408889634f;
             const f32x2_t e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
             const f32x2_t d = e + 1.0f;                      // 1 + exp2(.) == exp2(.) + 1 (commutative, one rounding)
             const f32x2_t q = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
             y = y * q;
+            const bf16x2_t h = {(__bf16)y.x, (__bf16)y.y};
+            r[j] = __builtin_bit_cast(uint32_t, h);
         }
-        const bf16x2_t h = {(__bf16)y.x, (__bf16)y.y};
-        r[j] = __builtin_bit_cast(uint32_t, h);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x2_t x = {__uint_as_float(w[j] << 16), __uint_as_float(w[j] & 0xFFFF0000u)};
+            const f32x2_t y = __builtin_elementwise_fma(av[j], x, bv[j]);
+            const bf16x2_t h = {(__bf16)y.x, (__bf16)y.y};
+            r[j] = __builtin_bit_cast(uint32_t, h);
+        }
     }
     return make_uint4(r[0], r[1], r[2], r[3]);
 }

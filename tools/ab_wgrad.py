@@ -1,5 +1,5 @@
 """Same-box A/B of rho_conv_nd_wgrad between two builds of the library (not a product path):
-tools/probe/librho_ref.so (a build of the committed tree) vs the in-tree librho_hip.so, alternated per case on random data,
+tools/probe/librho_head.so (a build of the committed tree; AB_REF overrides) vs the in-tree librho_hip.so, alternated per case on random data,
 with the two weight gradients compared.  usage (GPU box): python tools/ab_wgrad.py [B]"""
 import ctypes as C, os, sys, time
 R0 = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,7 +11,7 @@ dev = "cuda"
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 cases = {"64->64 @64^3": (64, 64, 64, 64, 64), "192->64 @64^3": (64, 64, 64, 192, 64), "128->128 @64x32x32": (64, 32, 32, 128, 128),
          "256->256 @64x16x16": (64, 16, 16, 256, 256), "512->512 @64x8x8": (64, 8, 8, 512, 512), "1024->512 @64x8x8": (64, 8, 8, 1024, 512)}
-libs = {"ref": C.CDLL(os.path.join(R0, "tools/probe/librho_ref.so")), "new": C.CDLL(os.path.join(R0, "rho_diffusion_amd/librho_hip.so"))}
+libs = {"ref": C.CDLL(os.path.join(R0, os.environ.get("AB_REF", "tools/probe/librho_head.so"))), "new": C.CDLL(os.path.join(R0, "rho_diffusion_amd/librho_hip.so"))}
 for extra in os.environ.get("AB_EXTRA", "").split():          # e.g. AB_EXTRA=tools/probe/libwgrad_m16.so (timing-only probes)
     libs[os.path.basename(extra)] = C.CDLL(os.path.join(R0, extra))
 ZERO = os.environ.get("AB_ZERO") == "1"                       # all-zero operands: no data-dependent power draw (clock probe)
