@@ -199,11 +199,15 @@ typedef struct rho_conv_desc {
      * taps of output row 2i + a read only two source rows (a = 0: rows i-1, i with weights w0, w1 + w2; a = 1: rows i, i+1 with
      * w0 + w1, w2), so one launch per parity runs a 2-tap axis (kh / kw = 2, weights from rho_prep_conv_weight_phase) on the
      * SOURCE tensor and writes every second output row / column: 12 instead of 27 taps in 3-D.  ph_h / ph_w: 0 = axis not
-     * upsampled, 1 / 2 = parity 0 / 1.  y (and res, stats) describe the full-resolution output [N, D, 2H, 2W, cout]. */
+     * upsampled, 1 / 2 = parity 0 / 1.  y (and res, stats) describe the full-resolution output [N, D, 2H, 2W, cout].
+     * A 1-tap phased axis (kh / kw = 1, taps start at the output row) is the even parity of a stride-2 conv's data gradient, see
+     * rho_prep_conv_weight_sel. */
     int32_t ph_h, ph_w;
     /* data gradient of such a phase: the input (dY of the full-resolution output) is read at parity phd - 1 of the phased axis
      * (d.h / d.w_ are the source-resolution extents, the tensor has twice as many rows / columns), 2-tap axis, taps start
-     * phd - 1 rows before the output position, dense output; the four launches accumulate into dX through `res`. */
+     * phd - 1 rows before the output position, dense output; the four launches accumulate into dX through `res`.  With kh / kw
+     * = 1 (one tap at the output row) or 2 this is also the forward of a stride-2 conv split by input parity
+     * (rho_prep_conv_weight_sel). */
     int32_t phd_h, phd_w;
     /* --- GroupNorm BACKWARD reduction fused into a dgrad launch (the output is d act(a * x + b), x the forward input): with
      * gnb_x1 set, `stats` receives per tile and channel  row 0 = sum of dz,  row 1 = sum of dz * x  (dz = output * act'(a x + b),
@@ -230,6 +234,18 @@ int rho_conv_nd_fwd(const rho_conv_desc* desc, void* stream);
  * columns] with flipped taps and transposed channels (as rho_prep_conv_weight_dgrad), for a launch with phd_h / phd_w. */
 int rho_prep_conv_weight_phase(const float* w, void* out, int dtype, int64_t cout, int64_t cin, int kd, int kh, int kw, int ph_h,
                                int ph_w, int64_t coutp, int64_t cinp, int dgrad, void* stream);
+
+/* Parity split of a STRIDE-2 conv (Downsample, unet_v2.py:153-162), again on stride-1 launches.  Per strided axis
+ * y[o] = w0 x[2o-1] + w1 x[2o] + w2 x[2o+1]:
+ *   forward  = one launch per INPUT parity, accumulated through `res` (rho_conv_desc.phd_h: even rows: 1 tap {w1}; odd rows:
+ *              2 taps {w0, w2} starting one row before the output row) - the loader never stages the 2x halo of a strided tile;
+ *   backward = one launch per parity of dX (rho_conv_desc.ph_h: dx[2m] = w1 dy[m]; dx[2m+1] = w2 dy[m] + w0 dy[m+1]) instead of
+ *              a 27-tap conv over a zero-stuffed dY in which three of four multiply-adds are zeros.
+ * This packs the taps such a launch uses: new tap r of an axis is source tap (sel >> 4r) & 15 (kh2 / kw2 new taps; an axis that
+ * keeps its taps passes its size and 0x210); flip_d mirrors the depth taps (data gradient); dgrad selects the data-gradient
+ * layout [taps][ceil32(cin)][ceilCK(cout)] instead of [taps][coutp][cinp]. */
+int rho_prep_conv_weight_sel(const float* w, void* out, int dtype, int64_t cout, int64_t cin, int kd, int kh, int kw, int kh2, int kw2,
+                             int sel_h, int sel_w, int flip_d, int64_t coutp, int64_t cinp, int dgrad, void* stream);
 
 /* Number of output tiles per sample the launch of `desc` uses (the middle extent of desc->stats), or 0 when fused
  * statistics are not available for this geometry (channel-major outputs, tiles that straddle samples: 1-D / 2-D

@@ -1069,7 +1069,8 @@ int launch_one(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
 // np = halo positions of the chosen tile.  BM = 128 runs 8 waves (slots per thread: 5 for np <= 640, else 14).
 template <typename T, int KD, int KH, int KW>
 int launch_bm(const ConvK& k, int BM, int np, dim3 grid, size_t lds, bool m16, hipStream_t st) {
-    constexpr bool PHASE = (KH == 2 || KW == 2);     // sub-pixel phase kernels: stride 1, 2-tap axes - the small-halo variants only
+    // sub-pixel phase kernels (2-tap axes; 3x1x1: the even-even parity of a stride-2 split): stride 1 - the small-halo variants only
+    constexpr bool PHASE = (KH == 2 || KW == 2 || (KD == 3 && KH == 1 && KW == 1));
     if constexpr (PHASE) { if (np > 640) return RHO_E_SHAPE; }
     if constexpr (sizeof(T) == 2 && KD * KH * KW > 1 && (KD * KH * KW) % 3 == 0) {
         // bf16, stride 1, no upsampling, regular halo: the 16x16x32 MFMA layout (holds a higher clock under load)
@@ -1103,6 +1104,10 @@ int launch_taps(const rho_conv_desc& d, const ConvK& k, int BM, int np, dim3 gri
     if (d.kd == 3 && d.kh == 2 && d.kw == 2) return launch_bm<T, 3, 2, 2>(k, BM, np, grid, lds, m16, st);
     if (d.kd == 1 && d.kh == 2 && d.kw == 2) return launch_bm<T, 1, 2, 2>(k, BM, np, grid, lds, m16, st);
     if (d.kd == 1 && d.kh == 1 && d.kw == 2) return launch_bm<T, 1, 1, 2>(k, BM, np, grid, lds, m16, st);
+    // parity split of a 3-D stride-2 conv (1- and 2-tap inner axes)
+    if (d.kd == 3 && d.kh == 1 && d.kw == 1) return launch_bm<T, 3, 1, 1>(k, BM, np, grid, lds, m16, st);
+    if (d.kd == 3 && d.kh == 1 && d.kw == 2) return launch_bm<T, 3, 1, 2>(k, BM, np, grid, lds, m16, st);
+    if (d.kd == 3 && d.kh == 2 && d.kw == 1) return launch_bm<T, 3, 2, 1>(k, BM, np, grid, lds, m16, st);
     return RHO_E_ARG;
 }
 
@@ -1130,12 +1135,15 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
     if (d.n <= 0 || d.d <= 0 || d.h <= 0 || d.w_ <= 0) return RHO_E_ARG;
     // sub-pixel phases: a 2-tap axis at the source resolution, stride 1, the output rows of one parity
     if (d.ph_h < 0 || d.ph_h > 2 || d.ph_w < 0 || d.ph_w > 2) return RHO_E_ARG;
-    if ((d.ph_h && (d.kh != 2 || d.sh != 1 || d.up_h || d.zs_h)) || (d.ph_w && (d.kw != 2 || d.sw != 1 || d.up_w || d.zs_w))) return RHO_E_ARG;
+    if ((d.ph_h && ((d.kh != 2 && d.kh != 1) || d.sh != 1 || d.up_h || d.zs_h)) || (d.ph_w && ((d.kw != 2 && d.kw != 1) || d.sw != 1 || d.up_w || d.zs_w)))
+        return RHO_E_ARG;
     if ((!d.ph_h && !d.phd_h && d.kh == 2) || (!d.ph_w && !d.phd_w && d.kw == 2)) return RHO_E_ARG;
     if ((d.ph_h || d.ph_w) && (d.split != d.cout || d.kd == 2)) return RHO_E_ARG;      // channels-last outputs only
     if (d.phd_h < 0 || d.phd_h > 2 || d.phd_w < 0 || d.phd_w > 2) return RHO_E_ARG;
-    if ((d.phd_h && (d.kh != 2 || d.sh != 1 || d.up_h || d.zs_h || d.ph_h)) || (d.phd_w && (d.kw != 2 || d.sw != 1 || d.up_w || d.zs_w || d.ph_w)))
+    if ((d.phd_h && ((d.kh != 2 && d.kh != 1) || d.sh != 1 || d.up_h || d.zs_h || d.ph_h)) ||
+        (d.phd_w && ((d.kw != 2 && d.kw != 1) || d.sw != 1 || d.up_w || d.zs_w || d.ph_w)))
         return RHO_E_ARG;
+    if ((d.ph_h || d.phd_h || d.ph_w || d.phd_w) && d.kd * d.kh * d.kw == 1) return RHO_E_ARG;   // (the 1x1x1 path merges the axes)
     if ((d.phd_h || d.phd_w) && (d.kd == 2 || d.pre_a)) return RHO_E_ARG;
 
     // output extents per sample (padding k/2).  Zero-stuffed input (dgrad of a stride-2 conv): the
@@ -1153,8 +1161,9 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
     //   1x1x1: everything is one long W axis;  1xkxk: depth*batch is the tile's depth axis.
     ConvK k{};
     int gridz = d.n;
-    k.pad_h = d.ph_h ? 2 - d.ph_h : d.phd_h ? d.phd_h - 1 : d.kh / 2;
-    k.pad_w = d.ph_w ? 2 - d.ph_w : d.phd_w ? d.phd_w - 1 : d.kw / 2;
+    // (a 1-tap phased axis sits on the output row: the even parity of a stride-2 conv's forward / data gradient)
+    k.pad_h = d.kh == 1 ? 0 : d.ph_h ? 2 - d.ph_h : d.phd_h ? d.phd_h - 1 : d.kh / 2;
+    k.pad_w = d.kw == 1 ? 0 : d.ph_w ? 2 - d.ph_w : d.phd_w ? d.phd_w - 1 : d.kw / 2;
     k.iy_mul = d.phd_h ? 2 : 1; k.iy_add = d.phd_h ? d.phd_h - 1 : 0;
     k.ix_mul = d.phd_w ? 2 : 1; k.ix_add = d.phd_w ? d.phd_w - 1 : 0;
     k.oy_mul = d.ph_h ? 2 : 1; k.oy_add = d.ph_h ? d.ph_h - 1 : 0;

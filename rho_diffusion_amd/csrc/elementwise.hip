@@ -562,6 +562,48 @@ extern "C" int rho_prep_conv_weight_phase(const float* w, void* out, int dtype, 
     return 0;
 }
 
+// Tap selection for the parity splits of a stride-2 conv (rho_prep_conv_weight_sel): new tap r of an axis takes source tap
+// sel >> (4 * r) & 15 of the 3-tap parameter (an axis that keeps its taps passes kh2 = kh and the identity selection).
+template <typename T>
+__global__ __launch_bounds__(256) void k_prep_w_sel(const float* __restrict__ w, T* __restrict__ out, int64_t cout, int64_t cin, int kd,
+                                                    int kh, int kw, int kh2, int kw2, int sel_h, int sel_w, int flip_d, int64_t d1,
+                                                    int64_t d2, int dgrad) {
+    const int64_t taps2 = (int64_t)kd * kh2 * kw2, taps = (int64_t)kd * kh * kw;
+    const int64_t total = taps2 * d1 * d2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i2 = i % d2, i1 = (i / d2) % d1;
+        const int tap = (int)(i / (d2 * d1));
+        const int c2 = tap % kw2, r2 = (tap / kw2) % kh2, dz = tap / (kw2 * kh2);
+        const int ks = ((flip_d ? kd - 1 - dz : dz) * kh + ((sel_h >> (4 * r2)) & 15)) * kw + ((sel_w >> (4 * c2)) & 15);
+        const int64_t co = dgrad ? i2 : i1, ci = dgrad ? i1 : i2;
+        float v = 0.0f;
+        if (co < cout && ci < cin) v = w[(co * cin + ci) * taps + ks];
+        out[i] = cvt_out<T>(v);
+    }
+}
+
+extern "C" int rho_prep_conv_weight_sel(const float* w, void* out, int dtype, int64_t cout, int64_t cin, int kd, int kh, int kw, int kh2,
+                                        int kw2, int sel_h, int sel_w, int flip_d, int64_t coutp, int64_t cinp, int dgrad, void* stream) {
+    if (!w || !out || cout <= 0 || cin <= 0 || kd <= 0 || kh <= 0 || kw <= 0 || kh2 <= 0 || kw2 <= 0 || kh2 > 4 || kw2 > 4 || cinp < cin ||
+        coutp < cout)
+        return RHO_E_ARG;
+    for (int r = 0; r < kh2; ++r) if (((sel_h >> (4 * r)) & 15) >= kh) return RHO_E_ARG;
+    for (int c = 0; c < kw2; ++c) if (((sel_w >> (4 * c)) & 15) >= kw) return RHO_E_ARG;
+    const int64_t d1 = dgrad ? cinp : coutp, d2 = dgrad ? coutp : cinp;
+    const int64_t total = (int64_t)kd * kh2 * kw2 * d1 * d2;
+    dim3 grid(grid_for(total, 256)), block(256);
+    if (dtype == RHO_BF16)
+        hipLaunchKernelGGL(k_prep_w_sel<bf16_raw>, grid, block, 0, as_stream(stream), w, (bf16_raw*)out, cout, cin, kd, kh, kw, kh2, kw2, sel_h, sel_w,
+                           flip_d, d1, d2, dgrad);
+    else if (dtype == RHO_F32)
+        hipLaunchKernelGGL(k_prep_w_sel<float>, grid, block, 0, as_stream(stream), w, (float*)out, cout, cin, kd, kh, kw, kh2, kw2, sel_h, sel_w,
+                           flip_d, d1, d2, dgrad);
+    else
+        return RHO_E_ARG;
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
 // ================================================================================================ backward helpers
 
 // dgrad weights: out[tap'][ci][co'] = w[src(co')][ci][taps-1-tap']  (flipped taps, transposed channels), so that the

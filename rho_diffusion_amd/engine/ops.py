@@ -241,6 +241,30 @@ def prep_conv_weight_phase(w: Tensor, dtype: torch.dtype, phase_hw: Tuple[int, i
     return out
 
 
+def prep_conv_weight_sel(w: Tensor, dtype: torch.dtype, sel_hw, *, flip_d: bool = False, dgrad: bool = False,
+                         out: Optional[Tensor] = None) -> Tensor:
+    """Tap selection of a 3-tap parameter for the parity splits of a stride-2 conv (rho_prep_conv_weight_sel): sel_hw = (taps of H,
+    taps of W), each a tuple of source tap indices (None keeps the axis)."""
+    _f32c(w, "w")
+    cout, cin = w.shape[0], w.shape[1]
+    k = [1] * (5 - w.dim()) + [int(v) for v in w.shape[2:]]
+    sh = tuple(range(k[1])) if sel_hw[0] is None else tuple(sel_hw[0])
+    sw = tuple(range(k[2])) if sel_hw[1] is None else tuple(sel_hw[1])
+    code = lambda t: sum(int(v) << (4 * i) for i, v in enumerate(t))      # noqa: E731
+    ck = elem_chunk(dtype)
+    taps2 = k[0] * len(sh) * len(sw)
+    if dgrad:
+        cinp, coutp = ((cin + 31) // 32) * 32, ((cout + ck - 1) // ck) * ck
+        shape = (taps2, cinp, coutp)
+    else:
+        cinp, coutp = ((cin + ck - 1) // ck) * ck, ((cout + 31) // 32) * 32
+        shape = (taps2, coutp, cinp)
+    out = torch.empty(*shape, dtype=dtype, device=w.device) if out is None else out
+    check(hip.lib().rho_prep_conv_weight_sel(ptr(w), ptr(out), dtype_code(dtype), cout, cin, k[0], k[1], k[2], len(sh), len(sw), code(sh),
+                                             code(sw), int(flip_d), coutp, cinp, int(dgrad), stream()), "rho_prep_conv_weight_sel")
+    return out
+
+
 # ----------------------------------------------------------------------------- GroupNorm
 def gn_nblk(s: int) -> int:
     return int(hip.lib().rho_gn_nblk(s))

@@ -66,6 +66,8 @@ class _ConvW:
         self.zero_bias: Optional[Tensor] = None
         self.wph: Optional[list] = None      # sub-pixel phase weights [(phase_hw, tensor)] of a conv behind a nearest x2 upsample
         self.wphd: Optional[list] = None     # ... and their data-gradient layouts (training plans)
+        self.ws2: Optional[list] = None      # parity split of a stride-2 conv: forward taps per input parity
+        self.ws2d: Optional[list] = None     # ... data-gradient taps per parity of dX
         self.refresh()
 
     def _geometry(self) -> None:          # subclasses re-interpret the parameter (see _StemAsGemm / _HeadAsGemm)
@@ -97,6 +99,21 @@ class _ConvW:
             if self.zero_bias is None:
                 self.zero_bias = torch.zeros(((self.cin + 31) // 32) * 32, dtype=torch.float32, device=self.w.device)
 
+    S2_FWD = {0: (1,), 1: (0, 2)}        # taps of the stride-2 forward on the even / odd input rows of a strided axis
+    S2_BWD = {0: (1,), 1: (2, 0)}        # taps of its data gradient on the even / odd rows of dX
+
+    def enable_s2(self, dgrad: bool = False) -> None:
+        """3-D stride-(1, 2, 2) conv as stride-1 launches per parity (rho_prep_conv_weight_sel)."""
+        if self.ws2 is None:
+            self.ws2 = [((a, b), ops.prep_conv_weight_sel(self._source(), self.dtype, (self.S2_FWD[a], self.S2_FWD[b])))
+                        for a in (0, 1) for b in (0, 1)]
+            self.zero_b = torch.zeros(self.coutp, dtype=torch.float32, device=self.w.device)
+        if dgrad and self.ws2d is None:
+            self.ws2d = [((a, b), ops.prep_conv_weight_sel(self._source(), self.dtype, (self.S2_BWD[a], self.S2_BWD[b]), flip_d=True,
+                                                           dgrad=True)) for a in (0, 1) for b in (0, 1)]
+            if self.zero_bias is None:
+                self.zero_bias = torch.zeros(((self.cin + 31) // 32) * 32, dtype=torch.float32, device=self.w.device)
+
     def _refresh_dgrad(self) -> None:
         w = self.weight.detach()
         w = w if w.is_contiguous() else w.contiguous()
@@ -118,6 +135,12 @@ class _ConvW:
         if self.wphd is not None:
             for ph, t in self.wphd:
                 ops.prep_conv_weight_phase(self._source(), self.dtype, ph, out=t, dgrad=True)
+        if self.ws2 is not None:
+            for (a, b), t in self.ws2:
+                ops.prep_conv_weight_sel(self._source(), self.dtype, (self.S2_FWD[a], self.S2_FWD[b]), out=t)
+        if self.ws2d is not None:
+            for (a, b), t in self.ws2d:
+                ops.prep_conv_weight_sel(self._source(), self.dtype, (self.S2_BWD[a], self.S2_BWD[b]), flip_d=True, dgrad=True, out=t)
 
 
 class _StemAsGemm(_ConvW):
@@ -398,6 +421,8 @@ class _Plan:
         self.phase_upsample = os.environ.get("RHO_PHASE_UPSAMPLE", "1") != "0"
         self.phase_upsample_bwd = os.environ.get("RHO_PHASE_UPSAMPLE_BWD", "1") != "0"
         self.phase_min_wgs = int(os.environ.get("RHO_PHASE_MIN_WGS", "256"))
+        self.s2_split = os.environ.get("RHO_S2_SPLIT", "1") != "0"
+        self.s2_split_bwd = os.environ.get("RHO_S2_SPLIT_BWD", "1") != "0"
         # backward: GroupNorm's reductions (sum dz, sum dz * x) in the epilogue of the dgrad launch that produces dz (A/B switch)
         # - from RHO_FUSE_GN_BWD channels up (0 = never): on the 64-channel layers the extra epilogue VALU work (one sigmoid per
         # element) costs the issue-bound narrow tiles more than the separate reduce pass it replaces
@@ -533,7 +558,17 @@ class _Plan:
             phased = (self.phase_upsample and up_hw != (0, 0) and cpre is None and cx2 is None and split_ == cout and res is None
                       and res_add_off is None and all(cw.kernel[1 + i] == 3 for i in range(2) if up_hw[i])
                       and wgs_per_phase >= self.phase_min_wgs)
-            if phased:
+            # Downsample's stride-(1, 2, 2) conv as four stride-1 launches, one per input parity, accumulated in place: no 2x halo
+            # per strided tile (the strided loader ran 380 - 870 TF/s), same multiply-adds
+            s2 = (self.s2_split and tuple(stride_hw) == (2, 2) and tuple(cw.kernel) == (3, 3, 3) and up_hw == (0, 0) and cpre is None
+                  and cx2 is None and split_ == cout and res is None and res_add_off is None and x1.shape[2] % 2 == 0
+                  and x1.shape[3] % 2 == 0 and (N * Do * Ho * Wo // 256) * max(1, cw.coutp // 128) >= self.phase_min_wgs)
+            if s2:
+                cw.enable_s2(dgrad=self.train)
+                descs = [ops.make_conv_desc(cx1, None, wt, cw.b if i == 0 else cw.zero_b, kernel=(3, len(cw.S2_FWD[a]), len(cw.S2_FWD[b])),
+                                            cout=cout, split=split_, y=y, y2=None, res=y if i > 0 else None, phase_dgrad_hw=(a + 1, b + 1))
+                         for i, ((a, b), wt) in enumerate(cw.ws2)]
+            elif phased:
                 cw.enable_phases(up_hw, dgrad=self.train)
                 descs = [ops.make_conv_desc(cx1, None, wt, cw.b, kernel=(cw.kernel[0], 2 if ph[0] else cw.kernel[1], 2 if ph[1] else cw.kernel[2]),
                                             cout=cout, split=split_, y=y, y2=None, phase_hw=ph) for ph, wt in cw.wph]
@@ -548,9 +583,10 @@ class _Plan:
             if y is not None and split_ == cout and want_stats:
                 # GroupNorm statistics of the output ride along in the epilogue where the geometry allows it
                 tiles = int(L.rho_conv_stats_tiles(C.byref(descs[0])))       # (phases: all launches of this output together)
+                tiles = int(L.rho_conv_stats_tiles(C.byref(descs[-1]))) if s2 else tiles
                 if tiles > 0:
                     sbuf = buf(N * tiles * 2 * cout, dtype=torch.float32)
-                    for d in descs:
+                    for d in (descs[-1:] if s2 else descs):      # (parity split: the last launch stores the final values)
                         d.stats = sbuf.data_ptr()
                     self.tstats[y.data_ptr()] = (sbuf, tiles)
             npos_out = N * Do * Ho * Wo
@@ -561,14 +597,16 @@ class _Plan:
                 self.ops.append(lambda s, d=d: L.rho_conv_nd_fwd(C.byref(d), s))
                 taps_run = d.kd * d.kh * d.kw
                 self.info.append(dict(
-                    kind="conv3" if cw.taps > 1 else "conv1", taps=cw.taps, cin=cw.cin, cout=cout, positions=npos_out // len(descs),
-                    flops=2.0 * npos_out * cout * cw.cin * cw.taps / len(descs),          # algorithmic (unpadded) MACs * 2
-                    executed_flops=2.0 * npos_out * cout * cw.cin * taps_run / len(descs),
+                    kind="conv3" if cw.taps > 1 else "conv1", taps=cw.taps, cin=cw.cin, cout=cout,
+                    positions=npos_out if s2 else npos_out // len(descs),
+                    flops=(2.0 * npos_out * cout * cw.cin * taps_run if s2 else
+                           2.0 * npos_out * cout * cw.cin * cw.taps / len(descs)),         # algorithmic (unpadded) MACs * 2
+                    executed_flops=2.0 * npos_out * cout * cw.cin * taps_run / (1 if s2 else len(descs)),
                     bytes=float(esz) * (npos_in * cw.cin + npos_out * cout * (2 if res is not None else 1) / len(descs)
                                         + taps_run * cout * cw.cin)))
             self.nodes.append(dict(k="conv", cw=cw, x1=x1, x2=x2, y=y, y2=y2, stride_hw=stride_hw, up_hw=up_hw, pre=pre,
                                    pre_silu=pre_silu, res=res, res_add_off=res_add_off, stem=stem, out_dims=(N, Do, Ho, Wo),
-                                   xact=xact, phased=phased))
+                                   xact=xact, phased=phased, s2=s2))
             return y, y2
 
         rs_hw = (1, 1) if dims >= 2 else (0, 1)      # axes a Down/Upsample touches: H and W (3-D: depth stays), 1-D: W only
@@ -940,6 +978,20 @@ class _Plan:
                     emit(lambda s, a=a: L.rho_pool2x_sum(*a, s), "pool2x", nbytes=5.0 * esz * x1.numel())
                     written.add(key(x1))
                 pool.put(dact)
+            elif node.get("s2") and self.s2_split_bwd:
+                # stride-2 conv: one launch per parity of dX (dx[2m] = w1 dy[m]; dx[2m+1] = w2 dy[m] + w0 dy[m+1]) instead of a 27-tap
+                # conv over a zero-stuffed dY (three of four multiply-adds on zeros)
+                g1, acc1 = gradbuf(x1)
+                for (a, b), wt in cw.ws2d:
+                    kern = (3, len(cw.S2_BWD[a]), len(cw.S2_BWD[b]))
+                    d = ops.make_conv_desc(dY, None, wt, cw.zero_bias, kernel=kern, cout=cin, split=cin, y=g1, y2=None,
+                                           res=g1 if acc1 else None, phase_hw=(a + 1, b + 1))
+                    self.keep.append(d)
+                    self.fwd_descs.append(d)
+                    emit(lambda s, d=d: L.rho_conv_nd_fwd(C.byref(d), s), "dgrad",
+                         flops=2.0 * (dY.numel() // dyw) * cin * cw.cout * kern[0] * kern[1] * kern[2],
+                         nbytes=float(esz) * (dY.numel() + x1.numel() / 4 * (2 if acc1 else 1)))
+                written.add(key(x1))
             else:
                 g1, acc1 = gradbuf(x1)
                 g2, acc2 = gradbuf(x2) if x2 is not None else (None, False)

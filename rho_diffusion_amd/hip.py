@@ -58,6 +58,8 @@ SIGNATURES = {
     "rho_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
     "rho_pack_input": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     "rho_prep_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    "rho_prep_conv_weight_sel": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                        c_int64, c_int64, c_int, c_void_p]),
     "rho_prep_conv_weight_phase": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64,
                                           c_int, c_void_p]),
     "rho_gn_nblk": (c_int, [c_int64]),

@@ -197,6 +197,33 @@ def _run_layer(ops, case, check=True):
             assert rel_l2(from_cl(dxp, dims), gx) < tol_b, f"dgrad phases {name}"
             assert rel_l2(gradp, gw) < tol_b, f"wgrad phases {name}"
 
+    if dims == 3 and stride_hw == (2, 2) and pre is None and not residual and split_ == cout and not c2:
+        # the engine's forward / data gradient for Downsample's conv: stride-1 launches per parity (rho_prep_conv_weight_sel)
+        FW, BW = {0: (1,), 1: (0, 2)}, {0: (1,), 1: (2, 0)}
+        ys = torch.full((No, Do, Ho, Wo, cout), float("nan"), dtype=dtype, device=DEV)
+        zb0 = torch.zeros(wp.shape[1], device=DEV)
+        ckp = 32 if dtype == BF16 else 16
+        dys = to_cl(F.pad(dy, (0, 0) * dims + (0, (-cout) % ckp)) if cout % ckp else dy, dtype)
+        dxs = torch.full(tuple(x1cl.shape), float("nan"), dtype=dtype, device=DEV)
+        zbd = torch.zeros(((cin + 31) // 32) * 32, device=DEV)
+        ks = []
+        for i, (a, c) in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
+            wsf = ops.prep_conv_weight_sel(w.to(DEV), dtype, (FW[a], FW[c]))
+            df = ops.make_conv_desc(x1cl, None, wsf, bp if i == 0 else zb0, kernel=(3, len(FW[a]), len(FW[c])), cout=cout, split=cout,
+                                    y=ys, y2=None, res=ys if i > 0 else None, phase_dgrad_hw=(a + 1, c + 1))
+            wsb = ops.prep_conv_weight_sel(w.to(DEV), dtype, (BW[a], BW[c]), flip_d=True, dgrad=True)
+            db = ops.make_conv_desc(dys, None, wsb, zbd, kernel=(3, len(BW[a]), len(BW[c])), cout=cin, split=cin, y=dxs, y2=None,
+                                    phase_hw=(a + 1, c + 1))
+            ks.append((wsf, wsb, df, db))
+            variants.add(ops.conv_variant(df))
+            variants.add(ops.conv_variant(db))
+            if check:
+                ops.conv_launch(df)
+                ops.conv_launch(db)
+        if check:
+            assert rel_l2(from_cl(ys, dims), ref) < tol_f, f"fwd parity split {name}"
+            assert rel_l2(from_cl(dxs, dims), gx) < tol_b, f"dgrad parity split {name}"
+
     # ---------------- data gradient (w.r.t. the activated input; the GroupNorm backward is a separate kernel)
     ck = 32 if dtype == BF16 else 16
     dyp = F.pad(dy, (0, 0) * dims + (0, (-cout) % ck)) if cout % ck else dy      # dY rows are as wide as the dgrad weights expect

@@ -540,3 +540,53 @@ def test_upsample_conv_as_subpixel_phases(ops, dtype, kernel, shape, up, cin, co
     tb = 1.5e-2 if dtype == torch.bfloat16 else 5e-5
     assert rel_l2(grad, wtr.grad) <= tb
     assert rel_l2(dbias[:cout], br.grad) <= 1e-4
+
+
+S2_CASES = [((2, 4, 8, 8), 64, 64), ((1, 6, 16, 8), 128, 128), ((2, 3, 6, 10), 32, 64)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape,cin,cout", S2_CASES, ids=[f"{c[1]}to{c[2]}" for c in S2_CASES])
+def test_stride2_conv_as_parity_split(ops, dtype, shape, cin, cout):
+    """Downsample's 3-D conv (stride (1, 2, 2), unet_v2.py:153-162) on stride-1 launches: forward = one launch per INPUT parity
+    accumulated in place (even rows: tap w1; odd rows: taps w0, w2), data gradient = one launch per parity of dX (dx[2m] = w1 dy[m];
+    dx[2m+1] = w2 dy[m] + w0 dy[m+1]) - against torch's strided conv3d and its autograd.  Same tolerances as test_conv."""
+    N, D, H, W = shape
+    x = rnd(det_normal((N, D, H, W, cin), "s2_x").to(DEV), dtype).to(dtype)
+    wt = rnd(det_normal((cout, cin, 3, 3, 3), "s2_w").to(DEV) * 0.05, dtype)
+    b = det_normal((cout,), "s2_b").to(DEV)
+    xr = x.float().permute(0, 4, 1, 2, 3).clone().requires_grad_(True)
+    refc = F.conv3d(xr, wt, b, stride=(1, 2, 2), padding=1)
+    Ho, Wo = H // 2, W // 2
+    y = torch.full((N, D, Ho, Wo, cout), float("nan"), device=DEV, dtype=dtype)
+    coutp = ((cout + 31) // 32) * 32
+    bp = torch.zeros(coutp, device=DEV); bp[:cout] = b
+    zb = torch.zeros(coutp, device=DEV)
+    keep, i = [], 0
+    for a in (0, 1):
+        for c in (0, 1):
+            sel = ((1,) if a == 0 else (0, 2), (1,) if c == 0 else (0, 2))
+            ws = ops.prep_conv_weight_sel(wt, dtype, sel)
+            keep.append(ws)
+            d = ops.make_conv_desc(x, None, ws, bp if i == 0 else zb, kernel=(3, len(sel[0]), len(sel[1])), cout=cout, split=cout, y=y, y2=None,
+                                   res=y if i > 0 else None, phase_dgrad_hw=(a + 1, c + 1))
+            ops.conv_launch(d)
+            i += 1
+    assert rel_l2(y.float(), refc.detach().permute(0, 2, 3, 4, 1)) <= tol(dtype)
+    ck = 32 if dtype == torch.bfloat16 else 16
+    dyw = ((cout + ck - 1) // ck) * ck
+    dy = torch.zeros(N, D, Ho, Wo, dyw, device=DEV, dtype=dtype)
+    dy[..., :cout] = rnd(det_normal((N, D, Ho, Wo, cout), "s2_dy").to(DEV), dtype).to(dtype)
+    refc.backward(dy[..., :cout].float().permute(0, 4, 1, 2, 3))
+    dx = torch.full((N, D, H, W, cin), float("nan"), device=DEV, dtype=dtype)
+    zbd = torch.zeros(((cin + 31) // 32) * 32, device=DEV)
+    for a in (0, 1):
+        for c in (0, 1):
+            sel = ((1,) if a == 0 else (2, 0), (1,) if c == 0 else (2, 0))
+            wd = ops.prep_conv_weight_sel(wt, dtype, sel, flip_d=True, dgrad=True)
+            keep.append(wd)
+            dd = ops.make_conv_desc(dy, None, wd, zbd, kernel=(3, len(sel[0]), len(sel[1])), cout=cin, split=cin, y=dx, y2=None,
+                                    phase_hw=(a + 1, c + 1))
+            ops.conv_launch(dd)
+    assert not torch.isnan(dx.float()).any()
+    assert rel_l2(dx.float(), xr.grad.permute(0, 2, 3, 4, 1)) <= (1.5e-2 if dtype == torch.bfloat16 else 5e-5)
