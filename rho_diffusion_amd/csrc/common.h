@@ -24,8 +24,11 @@ __device__ __forceinline__ bf16_raw f32_to_bf16(float f) {
     return *reinterpret_cast<bf16_raw*>(&h);
 }
 
+// (as a 2-vector cast this is ONE v_cvt_pk_bf16_f32; two scalar casts + shift + or came out as 2 cvt + lshl + or_sdwa per pair)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_pack_t;
+    const bf16x2_pack_t h = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, h);
 }
 
 // x * sigmoid(x) with the hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each) instead of an IEEE

@@ -801,7 +801,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
             // barrier and the LDS reads instead of after them (one exposed global latency per tile otherwise).
             constexpr int NIT = 256 * PPR / NTHR;
             static_assert(256 * PPR % NTHR == 0, "whole items per thread");
-            long long eoff[NIT];
+            int eoff[NIT];                                   // output position (the host guarantees < 2^31 positions), -1 = outside
             uint4 rres[NIT];
             uint4 gx[NIT];                                  // gnb: this thread's piece of the forward input at its output positions
             float bia[PE];                                  // bias (+ the per-sample additive term, 3-D: one sample per tile)
@@ -842,13 +842,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                     const int pd = pp >> (p.lgTW + p.lgTH);
                     const int od = od0 + pd, oh = oh0 + ph, ow = ow0 + pw;
                     const bool ok = od < p.Do && oh < p.Ho && ow < p.Wo;
-                    const long long L = (((long long)n * p.Do + od) * p.Ho_out + (oh * p.oy_mul + p.oy_add)) * p.Wo_out + (ow * p.ox_mul + p.ox_add);
+                    const int L = ((n * p.Do + od) * p.Ho_out + (oh * p.oy_mul + p.oy_add)) * p.Wo_out + (ow * p.ox_mul + p.ox_add);
                     eoff[k] = ok ? L : -1;
                     rres[k] = make_uint4(0u, 0u, 0u, 0u);
-                    if (ok && p.res != nullptr)
-                        rres[k] = *reinterpret_cast<const uint4*>(p.res + ((size_t)L * p.split + co0 + piece * PE) * sizeof(T));
+                    if (ok && p.res != nullptr)     // (32 x 32 -> 64-bit multiply: one v_mad_u64_u32 instead of a 64 x 64 sequence)
+                        rres[k] = *reinterpret_cast<const uint4*>(p.res + ((size_t)(unsigned)L * (unsigned)p.split + (unsigned)(co0 + piece * PE)) * sizeof(T));
                     gx[k] = make_uint4(0u, 0u, 0u, 0u);
-                    if (ok && gnb_on) gx[k] = *reinterpret_cast<const uint4*>(gsrc + ((size_t)L * gcs + gch) * sizeof(T));
+                    if (ok && gnb_on) gx[k] = *reinterpret_cast<const uint4*>(gsrc + ((size_t)(unsigned)L * (unsigned)gcs + (unsigned)gch) * sizeof(T));
                 }
             }
             __syncthreads();
@@ -856,7 +856,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
             for (int k = 0; k < NIT; ++k) {
                 if (eoff[k] < 0) continue;
                 const int lr = tid / PPR + k * (NTHR / PPR), piece = tid % PPR;
-                const long long L = eoff[k];
+                const int L = eoff[k];
                 const int co = co0 + piece * PE;
                 float v[PE];
 #pragma unroll
@@ -866,14 +866,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                     v[q4 * 4 + 2] = a4.z + bia[q4 * 4 + 2]; v[q4 * 4 + 3] = a4.w + bia[q4 * 4 + 3];
                 }
                 if (KD != 3 && p.res_add != nullptr) {
-                    const long long ns = L / p.S_out;
+                    const long long ns = (long long)L / p.S_out;
 #pragma unroll
                     for (int q4 = 0; q4 < PE / 4; ++q4) {
                         const float4 e = *reinterpret_cast<const float4*>(p.res_add + ns * p.res_add_stride + co + q4 * 4);
                         v[q4 * 4 + 0] += e.x; v[q4 * 4 + 1] += e.y; v[q4 * 4 + 2] += e.z; v[q4 * 4 + 3] += e.w;
                     }
                 }
-                const size_t eo = (size_t)L * p.split + co;
+                const size_t eo = (size_t)(unsigned)L * (unsigned)p.split + (unsigned)co;
                 if constexpr (sizeof(T) == 2) {
                     if (p.res != nullptr) {
                         const uint4 r = rres[k];
