@@ -183,7 +183,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                 const int iw = r - ih * p.IW;
                 const int gd = gd_base + id;
                 int gh = gh_base + ih, gw = gw_base + iw;
-                bool ok = gd >= 0 && gd < p.D && gh >= 0 && gh < p.H && gw >= 0 && gw < p.W;
+                bool ok = ((unsigned)gd < (unsigned)p.D) & ((unsigned)gh < (unsigned)p.H) & ((unsigned)gw < (unsigned)p.W);
                 if (p.zs_h) { ok = ok && ((gh & 1) == 0) && ((gh >> 1) < p.Hs); gh >>= 1; }
                 if (p.zs_w) { ok = ok && ((gw & 1) == 0) && ((gw >> 1) < p.Ws); gw >>= 1; }
                 if (ok) {
@@ -761,9 +761,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
 #undef RHO_LOAD_WP
 #undef RHO_STORE_W
 #undef RHO_HALO_LOAD
+    // The epilogue reads its parameters (output / residual / bias / statistics pointers, output geometry) from the kernel-argument
+    // segment again instead of from `p`: held in SGPRs across the tap loop they pushed the kernel past the scalar register file
+    // (120 spills to VGPR lanes: ~300 v_readlane per tile in the set-up and 4 per epilogue item, all VALU issue slots).  The asm
+    // keeps the reloads below the loop.
+    const __attribute__((address_space(4))) ConvK* qp = (const __attribute__((address_space(4))) ConvK*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(qp));
+    const __attribute__((address_space(4))) ConvK& q = *qp;
     // ---- epilogue: lane holds, for position column (lane&31) of tile j, channels
     //      co0 + 32*mi + 8*rg + 4*half + {0,1,2,3}  in acc[mi][j][4*rg + {0..3}]
-    const bool cl_region = (co0 < p.split);
+    const bool cl_region = (co0 < q.split);
     if (cl_region) {
         // Channels-last output (every block of this launch region: BM divides split).  The accumulator layout gives a
         // lane 4 channels of one position, i.e. 8-byte stores (and residual loads) scattered over 32 rows per
@@ -806,28 +813,28 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
             uint4 gx[NIT];                                  // gnb: this thread's piece of the forward input at its output positions
             float bia[PE];                                  // bias (+ the per-sample additive term, 3-D: one sample per tile)
             float gna[PE], gnb[PE];                         // gnb: folded affine of the forward prologue, this thread's channels
-            const bool gnb_on = p.gnb_x1 != nullptr;
+            const bool gnb_on = q.gnb_x1 != nullptr;
             {
                 const int piece = tid % PPR;
                 const int gco = co0 + piece * PE;           // the piece lies in one concat source (widths are multiples of 32)
-                const bool g_first = gco < p.gnb_c1;
-                const char* const gsrc = g_first ? p.gnb_x1 : p.gnb_x2;
-                const int gcs = g_first ? p.gnb_c1 : p.split - p.gnb_c1, gch = g_first ? gco : gco - p.gnb_c1;
+                const bool g_first = gco < q.gnb_c1;
+                const char* const gsrc = g_first ? q.gnb_x1 : q.gnb_x2;
+                const int gcs = g_first ? q.gnb_c1 : q.split - q.gnb_c1, gch = g_first ? gco : gco - q.gnb_c1;
                 if (gnb_on) {
-                    const int nsg = n + bt / p.tps;         // the tile's sample (statistics are only fused for one-sample tiles)
+                    const int nsg = n + bt / q.tps;         // the tile's sample (statistics are only fused for one-sample tiles)
 #pragma unroll
                     for (int e = 0; e < PE; ++e) {
-                        gna[e] = p.gnb_a[(size_t)nsg * p.split + gco + e];
-                        gnb[e] = p.gnb_b[(size_t)nsg * p.split + gco + e];
+                        gna[e] = q.gnb_a[(size_t)nsg * q.split + gco + e];
+                        gnb[e] = q.gnb_b[(size_t)nsg * q.split + gco + e];
                     }
                 }
 #pragma unroll
                 for (int q4 = 0; q4 < PE / 4; ++q4) {
-                    const float4 b4 = *reinterpret_cast<const float4*>(p.bias + co0 + piece * PE + q4 * 4);
+                    const float4 b4 = *reinterpret_cast<const float4*>(q.bias + co0 + piece * PE + q4 * 4);
                     bia[q4 * 4 + 0] = b4.x; bia[q4 * 4 + 1] = b4.y; bia[q4 * 4 + 2] = b4.z; bia[q4 * 4 + 3] = b4.w;
                     if constexpr (KD == 3) {
-                        if (p.res_add != nullptr) {
-                            const float4 e = *reinterpret_cast<const float4*>(p.res_add + (long long)n * p.res_add_stride + co0 + piece * PE + q4 * 4);
+                        if (q.res_add != nullptr) {
+                            const float4 e = *reinterpret_cast<const float4*>(q.res_add + (long long)n * q.res_add_stride + co0 + piece * PE + q4 * 4);
                             bia[q4 * 4 + 0] += e.x; bia[q4 * 4 + 1] += e.y; bia[q4 * 4 + 2] += e.z; bia[q4 * 4 + 3] += e.w;
                         }
                     }
@@ -835,18 +842,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
 #pragma unroll
                 for (int k = 0; k < NIT; ++k) {
                     const int lr = tid / PPR + k * (NTHR / PPR);
-                    const int pp = M16 ? tile_position16((lr >> 6) * 4 + ((lr >> 4) & 3), lr & 15, p.TW, p.pair_lg)
-                                       : tile_position((lr >> 6) * 2 + ((lr >> 5) & 1), lr & 31, p.TW, p.pair_lg);
-                    const int pw = pp & (p.TW - 1);
-                    const int ph = (pp >> p.lgTW) & (p.TH - 1);
-                    const int pd = pp >> (p.lgTW + p.lgTH);
+                    const int pp = M16 ? tile_position16((lr >> 6) * 4 + ((lr >> 4) & 3), lr & 15, q.TW, q.pair_lg)
+                                       : tile_position((lr >> 6) * 2 + ((lr >> 5) & 1), lr & 31, q.TW, q.pair_lg);
+                    const int pw = pp & (q.TW - 1);
+                    const int ph = (pp >> q.lgTW) & (q.TH - 1);
+                    const int pd = pp >> (q.lgTW + q.lgTH);
                     const int od = od0 + pd, oh = oh0 + ph, ow = ow0 + pw;
-                    const bool ok = od < p.Do && oh < p.Ho && ow < p.Wo;
-                    const int L = ((n * p.Do + od) * p.Ho_out + (oh * p.oy_mul + p.oy_add)) * p.Wo_out + (ow * p.ox_mul + p.ox_add);
+                    const bool ok = od < q.Do && oh < q.Ho && ow < q.Wo;
+                    const int L = ((n * q.Do + od) * q.Ho_out + (oh * q.oy_mul + q.oy_add)) * q.Wo_out + (ow * q.ox_mul + q.ox_add);
                     eoff[k] = ok ? L : -1;
                     rres[k] = make_uint4(0u, 0u, 0u, 0u);
-                    if (ok && p.res != nullptr)     // (32 x 32 -> 64-bit multiply: one v_mad_u64_u32 instead of a 64 x 64 sequence)
-                        rres[k] = *reinterpret_cast<const uint4*>(p.res + ((size_t)(unsigned)L * (unsigned)p.split + (unsigned)(co0 + piece * PE)) * sizeof(T));
+                    if (ok && q.res != nullptr)     // (32 x 32 -> 64-bit multiply: one v_mad_u64_u32 instead of a 64 x 64 sequence)
+                        rres[k] = *reinterpret_cast<const uint4*>(q.res + ((size_t)(unsigned)L * (unsigned)q.split + (unsigned)(co0 + piece * PE)) * sizeof(T));
                     gx[k] = make_uint4(0u, 0u, 0u, 0u);
                     if (ok && gnb_on) gx[k] = *reinterpret_cast<const uint4*>(gsrc + ((size_t)(unsigned)L * (unsigned)gcs + (unsigned)gch) * sizeof(T));
                 }
@@ -865,17 +872,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                     v[q4 * 4 + 0] = a4.x + bia[q4 * 4 + 0]; v[q4 * 4 + 1] = a4.y + bia[q4 * 4 + 1];
                     v[q4 * 4 + 2] = a4.z + bia[q4 * 4 + 2]; v[q4 * 4 + 3] = a4.w + bia[q4 * 4 + 3];
                 }
-                if (KD != 3 && p.res_add != nullptr) {
-                    const long long ns = (long long)L / p.S_out;
+                if (KD != 3 && q.res_add != nullptr) {
+                    const long long ns = (long long)L / q.S_out;
 #pragma unroll
                     for (int q4 = 0; q4 < PE / 4; ++q4) {
-                        const float4 e = *reinterpret_cast<const float4*>(p.res_add + ns * p.res_add_stride + co + q4 * 4);
+                        const float4 e = *reinterpret_cast<const float4*>(q.res_add + ns * q.res_add_stride + co + q4 * 4);
                         v[q4 * 4 + 0] += e.x; v[q4 * 4 + 1] += e.y; v[q4 * 4 + 2] += e.z; v[q4 * 4 + 3] += e.w;
                     }
                 }
-                const size_t eo = (size_t)(unsigned)L * (unsigned)p.split + (unsigned)co;
+                const size_t eo = (size_t)(unsigned)L * (unsigned)q.split + (unsigned)co;
                 if constexpr (sizeof(T) == 2) {
-                    if (p.res != nullptr) {
+                    if (q.res != nullptr) {
                         const uint4 r = rres[k];
                         v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xFFFF0000u);
                         v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xFFFF0000u);
@@ -886,22 +893,22 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                     {   // streaming store: the 1 GB outputs do not fit the caches, keep L2 for the halo re-reads (whole step -0.5 %)
                         typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
                         const u32x4_nt ov = {o.x, o.y, o.z, o.w};
-                        __builtin_nontemporal_store(ov, reinterpret_cast<u32x4_nt*>(p.y + eo * 2));
+                        __builtin_nontemporal_store(ov, reinterpret_cast<u32x4_nt*>(q.y + eo * 2));
                     }
-                    if (p.stats != nullptr) {             // statistics of the values as stored (what a reader would see)
+                    if (q.stats != nullptr) {             // statistics of the values as stored (what a reader would see)
                         v[0] = __uint_as_float(o.x << 16); v[1] = __uint_as_float(o.x & 0xFFFF0000u);
                         v[2] = __uint_as_float(o.y << 16); v[3] = __uint_as_float(o.y & 0xFFFF0000u);
                         v[4] = __uint_as_float(o.z << 16); v[5] = __uint_as_float(o.z & 0xFFFF0000u);
                         v[6] = __uint_as_float(o.w << 16); v[7] = __uint_as_float(o.w & 0xFFFF0000u);
                     }
                 } else {
-                    if (p.res != nullptr) {
+                    if (q.res != nullptr) {
                         const uint4 r = rres[k];
                         v[0] += __uint_as_float(r.x); v[1] += __uint_as_float(r.y); v[2] += __uint_as_float(r.z); v[3] += __uint_as_float(r.w);
                     }
-                    *reinterpret_cast<float4*>(p.y + eo * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(q.y + eo * 4) = make_float4(v[0], v[1], v[2], v[3]);
                 }
-                if (p.stats != nullptr) {
+                if (q.stats != nullptr) {
                     if (gnb_on) {
                         // dgrad of a conv behind GroupNorm (+SiLU): v = d act(a x + b) as stored; the norm's backward needs the
                         // per-channel sums of dz = v * act'(a x + b) and of dz * x (rho_gn_bwd_finalize, fmt 1)
@@ -919,7 +926,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
 #pragma unroll
                         for (int e = 0; e < PE; ++e) {
                             float dz = v[e];
-                            if (p.gnb_silu) dz *= dsilu_f(fmaf(gna[e], xv[e], gnb[e]));
+                            if (q.gnb_silu) dz *= dsilu_f(fmaf(gna[e], xv[e], gnb[e]));
                             ssum[e] += dz;
                             ssq[e] = fmaf(dz, xv[e], ssq[e]);
                         }
@@ -933,7 +940,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                 }
             }
         }
-        if (p.stats != nullptr) {
+        if (q.stats != nullptr) {
             // threads tid = piece (mod PPR) hold partials of the same channels: combine through LDS in thread order
             // (fixed order => reproducible), one (channel, statistic) per finishing thread
             __syncthreads();
@@ -944,28 +951,28 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                 red[tid * (2 * PE) + PE + e] = ssq[e];
             }
             __syncthreads();
-            const int ns = n + bt / p.tps, ts = bt % p.tps + p.stats_off;
+            const int ns = n + bt / q.tps, ts = bt % q.tps + q.stats_off;
             for (int item = tid; item < PPR * 2 * PE; item += NTHR) {
                 const int piece = item / (2 * PE), e2 = item % (2 * PE);
                 float accv = 0.0f;
                 for (int q = 0; q < NTHR / PPR; ++q) accv += red[(q * PPR + piece) * (2 * PE) + e2];
                 const int stat = e2 / PE, ch = co0 + piece * PE + (e2 % PE);
-                p.stats[(((size_t)ns * p.tps + ts) * 2 + stat) * p.split + ch] = accv;
+                q.stats[(((size_t)ns * q.tps + ts) * 2 + stat) * q.split + ch] = accv;
             }
         }
         return;
     }
 #pragma unroll
     for (int jx = 0; jx < (M16 ? 4 : 2); ++jx) {
-        const int pp = M16 ? tile_position16(wpos * 4 + jx, lane & 15, p.TW, p.pair_lg) : tile_position(wpos * 2 + jx, lane & 31, p.TW, p.pair_lg);
-        const int pw = pp & (p.TW - 1);
-        const int ph = (pp >> p.lgTW) & (p.TH - 1);
-        const int pd = pp >> (p.lgTW + p.lgTH);
+        const int pp = M16 ? tile_position16(wpos * 4 + jx, lane & 15, q.TW, q.pair_lg) : tile_position(wpos * 2 + jx, lane & 31, q.TW, q.pair_lg);
+        const int pw = pp & (q.TW - 1);
+        const int ph = (pp >> q.lgTW) & (q.TH - 1);
+        const int pd = pp >> (q.lgTW + q.lgTH);
         const int od = od0 + pd, oh = oh0 + ph, ow = ow0 + pw;
-        if (od >= p.Do || oh >= p.Ho || ow >= p.Wo) continue;
-        const long long L = (((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
-        const long long ns = L / p.S_out;
-        const long long ps = L - ns * p.S_out;
+        if (od >= q.Do || oh >= q.Ho || ow >= q.Wo) continue;
+        const long long L = (((long long)n * q.Do + od) * q.Ho + oh) * q.Wo + ow;
+        const long long ns = L / q.S_out;
+        const long long ps = L - ns * q.S_out;
         const int j = M16 ? (jx >> 1) : jx;
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
@@ -974,60 +981,60 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                 const int rg = M16 ? 2 * rx + (jx & 1) : rx;
                 const int co = M16 ? co0 + wco * (BM / WCO) + 16 * (2 * mi + rx) + 4 * (lane >> 4)
                                    : co0 + wco * (BM / WCO) + mi * 32 + rg * 8 + half * 4;
-                const float4 bv = *reinterpret_cast<const float4*>(p.bias + co);
+                const float4 bv = *reinterpret_cast<const float4*>(q.bias + co);
                 float v0 = acc[mi][j][rg * 4 + 0] + bv.x;
                 float v1 = acc[mi][j][rg * 4 + 1] + bv.y;
                 float v2 = acc[mi][j][rg * 4 + 2] + bv.z;
                 float v3 = acc[mi][j][rg * 4 + 3] + bv.w;
                 if (cl_region) {
-                    if (p.res_add != nullptr) {
-                        const float4 e = *reinterpret_cast<const float4*>(p.res_add + ns * p.res_add_stride + co);
+                    if (q.res_add != nullptr) {
+                        const float4 e = *reinterpret_cast<const float4*>(q.res_add + ns * q.res_add_stride + co);
                         v0 += e.x; v1 += e.y; v2 += e.z; v3 += e.w;
                     }
-                    const size_t eo = (size_t)L * p.split + co;
+                    const size_t eo = (size_t)L * q.split + co;
                     if constexpr (sizeof(T) == 2) {
-                        if (p.res != nullptr) {
-                            const uint2 r = *reinterpret_cast<const uint2*>(p.res + eo * 2);
+                        if (q.res != nullptr) {
+                            const uint2 r = *reinterpret_cast<const uint2*>(q.res + eo * 2);
                             v0 += __uint_as_float(r.x << 16); v1 += __uint_as_float(r.x & 0xFFFF0000u);
                             v2 += __uint_as_float(r.y << 16); v3 += __uint_as_float(r.y & 0xFFFF0000u);
                         }
-                        *reinterpret_cast<uint2*>(p.y + eo * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                        *reinterpret_cast<uint2*>(q.y + eo * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
                     } else {
-                        if (p.res != nullptr) {
-                            const float4 r = *reinterpret_cast<const float4*>(p.res + eo * 4);
+                        if (q.res != nullptr) {
+                            const float4 r = *reinterpret_cast<const float4*>(q.res + eo * 4);
                             v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
                         }
-                        *reinterpret_cast<float4*>(p.y + eo * 4) = make_float4(v0, v1, v2, v3);
+                        *reinterpret_cast<float4*>(q.y + eo * 4) = make_float4(v0, v1, v2, v3);
                     }
-                } else if (p.y2_cl) {
-                    const int w2 = p.cout - p.split;
-                    const size_t eo = (size_t)L * w2 + (co - p.split);
-                    if (co < p.cout) {                 // widths are multiples of 4: a 4-channel piece is all in or all out
+                } else if (q.y2_cl) {
+                    const int w2 = q.cout - q.split;
+                    const size_t eo = (size_t)L * w2 + (co - q.split);
+                    if (co < q.cout) {                 // widths are multiples of 4: a 4-channel piece is all in or all out
                         if constexpr (sizeof(T) == 2) {
-                            if (p.res2 != nullptr) {
-                                const uint2 r = *reinterpret_cast<const uint2*>(p.res2 + eo * 2);
+                            if (q.res2 != nullptr) {
+                                const uint2 r = *reinterpret_cast<const uint2*>(q.res2 + eo * 2);
                                 v0 += __uint_as_float(r.x << 16); v1 += __uint_as_float(r.x & 0xFFFF0000u);
                                 v2 += __uint_as_float(r.y << 16); v3 += __uint_as_float(r.y & 0xFFFF0000u);
                             }
-                            *reinterpret_cast<uint2*>(p.y2 + eo * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                            *reinterpret_cast<uint2*>(q.y2 + eo * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
                         } else {
-                            if (p.res2 != nullptr) {
-                                const float4 r = *reinterpret_cast<const float4*>(p.res2 + eo * 4);
+                            if (q.res2 != nullptr) {
+                                const float4 r = *reinterpret_cast<const float4*>(q.res2 + eo * 4);
                                 v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
                             }
-                            *reinterpret_cast<float4*>(p.y2 + eo * 4) = make_float4(v0, v1, v2, v3);
+                            *reinterpret_cast<float4*>(q.y2 + eo * 4) = make_float4(v0, v1, v2, v3);
                         }
                     }
                 } else {
                     const float vv[4] = {v0, v1, v2, v3};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (co + e < p.cout) {
-                            const size_t eo = ((size_t)ns * (p.cout - p.split) + (co + e - p.split)) * p.S_out + ps;
-                            if (p.y2_f32 || sizeof(T) == 4)
-                                reinterpret_cast<float*>(p.y2)[eo] = vv[e];
+                        if (co + e < q.cout) {
+                            const size_t eo = ((size_t)ns * (q.cout - q.split) + (co + e - q.split)) * q.S_out + ps;
+                            if (q.y2_f32 || sizeof(T) == 4)
+                                reinterpret_cast<float*>(q.y2)[eo] = vv[e];
                             else
-                                reinterpret_cast<bf16_raw*>(p.y2)[eo] = f32_to_bf16(vv[e]);
+                                reinterpret_cast<bf16_raw*>(q.y2)[eo] = f32_to_bf16(vv[e]);
                         }
                     }
                 }
