@@ -94,13 +94,14 @@ if PMC_DIR != "pmc":
     sys.exit(0)
 
 # the launches bench.py files under kind "conv3": the 27-tap kernels and the 12-tap sub-pixel phases of the Upsample convs
-conv3 = [k for k in sq if "k_conv<" in k and ("3, 3, 3" in k or "3, 2, 2" in k)]
+# (... and the 1- / 2-tap parity launches of the stride-2 Downsample convs)
+conv3 = [k for k in sq if "k_conv<" in k and any(t in k for t in ("3, 3, 3", "3, 2, 2", "3, 1, 1", "3, 1, 2", "3, 2, 1"))]
 fetch = sum(sq[k].get("FETCH_SIZE", 0.0) for k in conv3) * 1024.0 * 2.0
 write = sum(sq[k].get("WRITE_SIZE", 0.0) for k in conv3) * 1024.0
 launches = sum(sq[k].get("_calls_fetch", 0) for k in conv3)
 mf = sum(sq[k].get("SQ_INSTS_MFMA", 0.0) * sq[k].get("mfma_cycles_per_inst_assumed", 32.0) for k in conv3)
 dsum = sum(DUR.get(k, 0.0) for k in conv3)
-tj = {"kernel": "k_conv<bf16,3,3,3,*> and <bf16,3,2,2,*> (all variants of the launches of kind conv3)", "build_id": meta.get("build_id"), "workload": meta.get("workload"),
+tj = {"kernel": "k_conv<bf16,3,{3|2|1},{3|2|1},*> (all variants of the launches bench.py files under kind conv3)", "build_id": meta.get("build_id"), "workload": meta.get("workload"),
       "mfma_util": (mf / (1024.0 * dsum * 2.4e9)) if dsum > 0 else None,
       "effective_clock_GHz": ({k[:60]: round(CLK[k], 3) for k in conv3 if k in CLK} or None),
       "mfma_util_note": "sum over the conv3 variants of SQ_INSTS_MFMA x SIMD cycles per instruction / (1024 SIMDs x summed kernel time "
