@@ -590,3 +590,63 @@ def test_stride2_conv_as_parity_split(ops, dtype, shape, cin, cout):
             ops.conv_launch(dd)
     assert not torch.isnan(dx.float()).any()
     assert rel_l2(dx.float(), xr.grad.permute(0, 2, 3, 4, 1)) <= (1.5e-2 if dtype == torch.bfloat16 else 5e-5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("kind", ["3d_concat", "1x1"])
+def test_groupnorm_backward_reduction_fused_into_dgrad(ops, dtype, kind):
+    """rho_conv_desc.gnb_*: a dgrad launch whose output is d act(a x + b) also writes, per tile and channel, sum dz and sum dz * x
+    (dz = output * act'(a x + b)); rho_gn_bwd_finalize(fmt = 1) on those sums must give the same apply coefficients and parameter
+    gradients as the separate rho_gn_bwd_reduce pass (fmt = 0) over the same tensors.  (An identity 'weight' makes the launch's
+    output a chosen tensor; 3-D with a concatenated forward input, and the 1x1x1 path.)"""
+    from rho_diffusion_amd import hip
+    L = hip.lib()
+    N, C1, C2 = 2, 64, 64
+    C = C1 + C2
+    shape = (N, 4, 8, 8) if kind == "3d_concat" else (N, 1, 16, 16)
+    S = shape[1] * shape[2] * shape[3]
+    kernel = (3, 3, 3) if kind == "3d_concat" else (1, 1, 1)
+    x1 = rnd(det_normal(shape + (C1,), "gb_x1").to(DEV), dtype).to(dtype)
+    x2 = rnd(det_normal(shape + (C2,), "gb_x2").to(DEV) + 0.5, dtype).to(dtype)
+    dact_src = rnd(det_normal(shape + (C,), "gb_g").to(DEV), dtype).to(dtype)
+    a = (1 + 0.3 * det_normal((N, C), "gb_a")).to(DEV)
+    b = (0.2 * det_normal((N, C), "gb_b")).to(DEV)
+    gamma, beta = (1 + 0.1 * det_normal((C,), "gb_ga")).to(DEV), (0.1 * det_normal((C,), "gb_be")).to(DEV)
+    xcat = torch.cat([x1.float(), x2.float()], -1).reshape(N, S, 32, C // 32)
+    mean = xcat.mean((1, 3))
+    rstd = (xcat.var((1, 3), unbiased=False) + 1e-5).rsqrt()
+    stats = torch.stack([mean, rstd], -1).contiguous()
+    # identity weights: centre tap = I
+    wt = torch.zeros((C, C) + kernel, device=DEV)
+    ctr = tuple(k // 2 for k in kernel)
+    wt[(torch.arange(C), torch.arange(C)) + ctr] = 1.0
+    w = ops.prep_conv_weight(wt, dtype)
+    dact = torch.empty(shape + (C,), device=DEV, dtype=dtype)
+    d = ops.make_conv_desc(dact_src, None, w, torch.zeros(C, device=DEV), kernel=kernel, cout=C, split=C, y=dact, y2=None)
+    tiles = ops.conv_stats_tiles(d)
+    assert tiles > 0
+    sbuf = torch.zeros(N * tiles * 2 * C, device=DEV)
+    d.stats = sbuf.data_ptr()
+    d.gnb_x1, d.gnb_x2, d.gnb_c1 = x1.data_ptr(), x2.data_ptr(), C1
+    d.gnb_a, d.gnb_b, d.gnb_silu = a.data_ptr(), b.data_ptr(), 1
+    ops.conv_launch(d)
+    assert torch.equal(dact, dact_src)
+    outs = []
+    for fmt in (0, 1):
+        work = torch.zeros(2 * N * C, device=DEV)
+        cA, cP, cQ = torch.zeros(N, C, device=DEV), torch.zeros(N, 32, device=DEV), torch.zeros(N, 32, device=DEV)
+        dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        if fmt == 0:
+            nblk = ops.gn_nblk(S)
+            part = torch.zeros(N * nblk * (C // 8) * 16, device=DEV)
+            hip.check(L.rho_gn_bwd_reduce(dact.data_ptr(), x1.data_ptr(), C1, x2.data_ptr(), C2, hip.dtype_code(dtype), N, S, a.data_ptr(),
+                                          b.data_ptr(), stats.data_ptr(), 1, part.data_ptr(), hip.stream()), "reduce")
+            src, nb = part, nblk
+        else:
+            src, nb = sbuf, tiles
+        hip.check(L.rho_gn_bwd_finalize(src.data_ptr(), N, C, S, nb, fmt, gamma.data_ptr(), beta.data_ptr(), None, 0, stats.data_ptr(),
+                                        work.data_ptr(), dg.data_ptr(), db.data_ptr(), 0, None, None, 0, cA.data_ptr(), cP.data_ptr(),
+                                        cQ.data_ptr(), hip.stream()), "finalize")
+        outs.append((cA, cP, cQ, dg, db))
+    for u, v, nm in zip(outs[0], outs[1], ("cA", "cP", "cQ", "dgamma", "dbeta")):
+        assert rel_l2(v, u) <= (2e-3 if dtype == torch.bfloat16 else 1e-4), nm
