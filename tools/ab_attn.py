@@ -1,4 +1,4 @@
-"""Same-box A/B of rho_attention_fwd / rho_attention_bwd (not a product path): tools/probe/librho_ref.so (a build of the committed
+"""Same-box A/B of rho_attention_fwd / rho_attention_bwd (not a product path): tools/probe/librho_head.so (AB_REF overrides; a build of the committed
 tree) vs the in-tree library, c3 (T = 4096, ch = 128, B = 32) and c5 (T = 32768, ch = 64, B = 2) shapes, random data,
 outputs compared.  usage: python tools/ab_attn.py"""
 import ctypes as C, os, sys, time
@@ -9,7 +9,7 @@ from rho_diffusion_amd import hip  # noqa: F401
 
 dev = "cuda"
 vp = C.c_void_p
-libs = {"ref": C.CDLL(os.path.join(R0, "tools/probe/librho_ref.so")), "new": C.CDLL(os.path.join(R0, "rho_diffusion_amd/librho_hip.so"))}
+libs = {"ref": C.CDLL(os.path.join(R0, os.environ.get("AB_REF", "tools/probe/librho_head.so"))), "new": C.CDLL(os.path.join(R0, "rho_diffusion_amd/librho_hip.so"))}
 for (B, T, heads, ch) in ((32, 4096, 4, 128), (2, 32768, 4, 64)):
     Cc = heads * ch
     qk = (torch.randn(B, T, 2 * Cc, device=dev) * 0.5).to(torch.bfloat16)
