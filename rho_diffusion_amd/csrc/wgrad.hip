@@ -13,6 +13,7 @@
 //     ds_read_b64_tr_b16 straight from the row-major tiles - no transposed copies.
 // The exact-f32 variant (v_mfma_f32_32x32x2_f32) needs one k per lane, i.e. plain ds_read_b32.
 #include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -46,6 +47,7 @@ struct WgradK {
     // sub-pixel phase of a conv behind a nearest x2 upsample (rho_conv_desc.ph_h / ph_w): taps start pad_h / pad_w rows before
     // the output position; dY row of output row oh: oh * oy_mul + oy_add in a tensor of Ho_out x Wo_out rows per depth slice
     int pad_h, pad_w, oy_mul, oy_add, ox_mul, ox_add, Ho_out, Wo_out;
+    int xcd_map;        // 1: workgroups of one position slab (all cout tiles x cin chunks) on consecutive launch slots of one XCD
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -109,8 +111,22 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const int piece = tid & 3;
-    const int co0 = blockIdx.y * COT;
-    const int c = blockIdx.z * CK;        // input-channel chunk of this workgroup
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  The cout-tile x cin-chunk workgroups of one position
+    // slab read the same dY tile / X rows: with the plain 3-D grid the second chunk of a slab ran rounds later on whatever XCD and
+    // fetched its half of every 128-byte line from HBM again.  Here the launch slots k = L / 8 of XCD e = L % 8 walk slab
+    // (k / pairs) * 8 + e through all its pairs back to back, so they run side by side out of one L2.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_map) {
+        const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int pairs = gridDim.y * gridDim.z;
+        const int e = L & 7, k = L >> 3;
+        const int pi = k % pairs;
+        bx = (k / pairs) * 8 + e;
+        bz = pi % (int)gridDim.z;
+        by = pi / (int)gridDim.z;
+    }
+    const int co0 = by * COT;
+    const int c = bz * CK;        // input-channel chunk of this workgroup
     const char* src;
     int cs, csrc;
     if (c < p.c1) { src = p.x1; cs = p.c1; csrc = c; } else { src = p.x2; cs = p.c2; csrc = c - p.c1; }
@@ -195,7 +211,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
         for (int mi = 0; mi < MT; ++mi) arow[mi] = pp0 * DYP + ((mi * 64) ^ dy_swz(q)) + colb * 2;
     }
 
-    const int tile0 = blockIdx.x * p.tiles_per_block;
+    const int tile0 = bx * p.tiles_per_block;
     const int tile1 = min(tile0 + p.tiles_per_block, p.tiles_total);
 
     // Staging is software-pipelined across tiles: the global loads of tile t+1 (branch-free, padding lanes read a
@@ -205,7 +221,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     // bias gradient = channel sums of dY: the dY tile passes through this thread's registers anyway (8 rows x one
     // 16-byte channel piece per tile); only the workgroups of input-channel chunk 0 add them up (uniform branch)
     constexpr int DPE = 16 / (int)sizeof(T);
-    const bool do_bias = (p.dbias != nullptr) && (blockIdx.z == 0);
+    const bool do_bias = (p.dbias != nullptr) && (bz == 0);
     float bsum[DPE];
 #pragma unroll
     for (int e = 0; e < DPE; ++e) bsum[e] = 0.0f;
@@ -835,7 +851,8 @@ static int wgrad_impl(const rho_conv_desc* dp, const void* dy, int64_t dy_width,
     int splits = cdiv(4 * n_cu, pairs);
     double best = -1.0;
     for (int r = 3; r <= 6; ++r) {
-        const int sp = (r * n_cu) / pairs;
+        int sp = (r * n_cu) / pairs;
+        if (sp >= 8) sp &= ~7;                 // multiples of 8: the slab -> XCD map of the kernel needs whole groups of 8 slabs
         if (sp < 1) continue;
         const long long total = (long long)sp * pairs;
         const double eff = (double)total / (double)(cdiv((int)total, n_cu) * n_cu) - 0.002 * (r > 4 ? r - 4 : 4 - r);
@@ -847,6 +864,8 @@ static int wgrad_impl(const rho_conv_desc* dp, const void* dy, int64_t dy_width,
     splits = cdiv(k.tiles_total, k.tiles_per_block);
     if (cdiv(d.coutp, COT) > 65535 || cin / CK > 65535) return RHO_E_SHAPE;
     dim3 grid((unsigned)splits, (unsigned)cdiv(d.coutp, COT), (unsigned)(cin / CK));
+    static const bool xcd_env = !(getenv("RHO_WGRAD_XCD") && atoi(getenv("RHO_WGRAD_XCD")) == 0);
+    k.xcd_map = (xcd_env && splits % 8 == 0 && (long long)splits * pairs < (1LL << 31)) ? 1 : 0;
     const int maxp = cdiv(t.NP, 64);
     size_t lds = (size_t)(maxp <= 10 ? 10 : 28) * 64 * XP + 256 * DYP;
     if (d.dtype == RHO_BF16 && maxp <= 10 && !d.pre_a) lds *= 2;     // LDS-DMA path: double-buffered tiles (2 x 72 KB)
