@@ -29,8 +29,9 @@ __global__ __launch_bounds__(256, CH <= 128 ? 2 : 1) void k_attn_bf16(const bf16
     __shared__ __attribute__((aligned(16))) char v_lds[NCT * 32 * VP];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    int tile_, h, b;
+    attn_block(tile_, h, b);
+    const int q0 = tile_ * 128 + wave * 32;
     const int qi = q0 + col;
     const size_t row2c = (size_t)2 * C;
 

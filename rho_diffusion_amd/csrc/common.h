@@ -55,3 +55,21 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2).  The tiles of one (batch, head) pair all stream the same
+// K / V (or Q / dO) - 2 MB at T = 4096, ch = 128: with the plain grid its 32 tiles sat on all 8 XCDs, every L2 held 8 pairs' worth
+// and thrashed.  Launch slot k = L / 8 of XCD e = L % 8 takes tile k % tiles of pair (k / tiles) * 8 + e, so one XCD's 32 CUs walk one
+// pair at a time (needs heads * batch to be a multiple of 8; else the plain grid).
+__device__ __forceinline__ void attn_block(int& tile, int& h, int& b) {
+    tile = blockIdx.x; h = blockIdx.y; b = blockIdx.z;
+    const int pairs = gridDim.y * gridDim.z;
+    if ((pairs & 7) == 0) {
+        const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int e = L & 7, k = L >> 3;
+        tile = k % (int)gridDim.x;
+        const int pr = (k / (int)gridDim.x) * 8 + e;
+        h = pr % (int)gridDim.y;
+        b = pr / (int)gridDim.y;
+    }
+}
+

@@ -564,8 +564,19 @@ __global__ __launch_bounds__(256) void k_wgrad1(const WgradK p, long long npos, 
     char* const xpl = smem;                            // [4 chunks][TP rows][64 B]
     char* const dyt = smem + 4 * TP * XP;              // [TP rows][128 B], halves swapped on rows with bit 1 set
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-    const int co0 = blockIdx.y * 64;
-    const int cg0 = blockIdx.z * 128;                  // first input channel of this workgroup's group
+    // (slab -> XCD map as in k_wgrad: the cout-tile x channel-group workgroups of a position slab side by side on one XCD)
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_map) {
+        const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int pairs = gridDim.y * gridDim.z;
+        const int e = L & 7, k = L >> 3;
+        const int pi = k % pairs;
+        bx = (k / pairs) * 8 + e;
+        bz = pi % (int)gridDim.z;
+        by = pi / (int)gridDim.z;
+    }
+    const int co0 = by * 64;
+    const int cg0 = bz * 128;                          // first input channel of this workgroup's group
     const int nchunk = min(4, (p.cin - cg0) / 32);     // chunks that exist (cin is a multiple of 32)
 
     // staging geometry: X pieces idx = tid + 256*i -> (row = idx/16, chunk = (idx%16)/4, piece = idx%4)
@@ -588,7 +599,7 @@ __global__ __launch_bounds__(256) void k_wgrad1(const WgradK p, long long npos, 
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][r] = 0.0f;
-    const bool do_bias = (p.dbias != nullptr) && (blockIdx.z == 0);
+    const bool do_bias = (p.dbias != nullptr) && (bz == 0);
     float bsum[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bsum[e] = 0.0f;
@@ -617,7 +628,7 @@ __global__ __launch_bounds__(256) void k_wgrad1(const WgradK p, long long npos, 
             dv[i] = *reinterpret_cast<const uint4*>(dsrc + (size_t)pos * p.dyw * 2);
         }
     };
-    const int tile0 = blockIdx.x * tiles_per_block;
+    const int tile0 = bx * tiles_per_block;
     const int tile1 = min(tile0 + tiles_per_block, tiles_total);
     if (tile0 < tile1) issue(tile0);
     for (int tl = tile0; tl < tile1; ++tl) {
@@ -810,10 +821,13 @@ static int wgrad_impl(const rho_conv_desc* dp, const void* dy, int64_t dy_width,
         const int tiles_total = (int)((npos + 127) / 128);
         const int pairs = cdiv(d.coutp, 64) * cdiv(cin, 128);
         int splits = cdiv(1536, pairs);
+        if (splits >= 8) splits &= ~7;
         if (splits < 1) splits = 1;
         if (splits > tiles_total) splits = tiles_total;
         const int tpb = cdiv(tiles_total, splits);
         splits = cdiv(tiles_total, tpb);
+        static const bool xcd_env1 = !(getenv("RHO_WGRAD_XCD") && atoi(getenv("RHO_WGRAD_XCD")) == 0);
+        k1.xcd_map = (xcd_env1 && splits % 8 == 0 && (long long)splits * pairs < (1LL << 31)) ? 1 : 0;
         if (cdiv(d.coutp, 64) > 65535 || cdiv(cin, 128) > 65535) return RHO_E_SHAPE;
         dim3 grid((unsigned)splits, (unsigned)cdiv(d.coutp, 64), (unsigned)cdiv(cin, 128));
         if (g_wvariant != nullptr) {
