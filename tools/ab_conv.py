@@ -13,7 +13,8 @@ UP = {"128->128 up @64x32x32": (64, 32, 32, 128, 128), "512->512 up @64x8x8": (6
 cases = {"64->64 @64^3 +pre": (64, 64, 64, 64, 64, True), "64->64 @64^3": (64, 64, 64, 64, 64, False), "192->64 @64^3 +pre": (64, 64, 64, 192, 64, True),
          "128->128 @64x32x32 +pre": (64, 32, 32, 128, 128, True), "128->128 @64x32x32": (64, 32, 32, 128, 128, False),
          "256->256 @64x16x16 +pre": (64, 16, 16, 256, 256, True), "512->512 @64x8x8 +pre": (64, 8, 8, 512, 512, True),
-         "512->512 @64x8x8": (64, 8, 8, 512, 512, False)}
+         "512->512 @64x8x8": (64, 8, 8, 512, 512, False), "1024->512 @64x8x8 +pre": (64, 8, 8, 1024, 512, True),
+         "768->256 @64x16x16 +pre": (64, 16, 16, 768, 256, True)}
 libs = {"tree": C.CDLL(os.path.join(R0, "rho_diffusion_amd/librho_hip.so"))}
 libs["tree"].rho_conv_stats_tiles.restype = C.c_int64
 libs["tree"].rho_conv_stats_tiles.argtypes = [C.c_void_p]
