@@ -219,9 +219,21 @@ def roofline_of(plan, args):
     }
 
 
+def launch_self(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: this process becomes the launcher.  It starts N ranks
+    of this same script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would), relays rank 0's JSON
+    line and returns non-zero if any rank failed.  The parent never touches the GPU (no HIP call, no exec)."""
+    from rho_diffusion_amd.launch import spawn_ranks
+    return spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, json_only=True)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_self(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and not (args.gpus == 1 and "WORLD_SIZE" in os.environ):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher environment says WORLD_SIZE={world}")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
@@ -250,9 +262,13 @@ def main():
 
     results = {}
     roofline = None
-    if world > 1:   # warm-up collective (cf. xpu.py:374-375), not part of the sampling data path
+    ranks_counted = 1
+    if world > 1:   # warm-up collective (cf. xpu.py:374-375), not part of the sampling data path; it also counts the ranks
+        assert dist.get_world_size() == world, (dist.get_world_size(), world)
         w = torch.ones(8, device=device)
         dist.all_reduce(w)
+        ranks_counted = int(round(float(w[0].item())))
+        assert ranks_counted == world, f"process group reduced over {ranks_counted} ranks, expected {world}"
 
     def timed(step_fn, steps, warmup):
         """(wall seconds for `steps` steps, max over ranks; per-step HIP-event durations in ms on this rank).  The events sit on
@@ -401,7 +417,8 @@ def main():
         metric, unit, value, steps, dt = "training_samples_per_sec", "samples/s", world * B * r["steps"] / r["dt"], r["steps"], r["dt"]
 
     out = {
-        "metric": metric, "value": value, "unit": unit, "n_gpus": world,
+        "metric": metric, "value": value, "unit": unit, "n_gpus": dist.get_world_size() if dist.is_initialized() else 1,
+        "ranks_counted_by_all_reduce": ranks_counted,
         "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": workload_name(args, world), "global_batch": B * world,

@@ -1,0 +1,105 @@
+"""CPU tests of the one-process-per-GPU launcher behind ``python bench.py --gpus N`` (rho_diffusion_amd/launch.py;
+reference: the env-driven rank / world set-up of rho_diffusion/xpu.py:335-413): environment handed to the ranks,
+argument pass-through, stdout relay of rank 0 only, exit codes, and a 2-rank gloo rendezvous through it."""
+import io
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+from rho_diffusion_amd import launch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _script(tmp_path, body):
+    p = tmp_path / "rank_script.py"
+    p.write_text(textwrap.dedent(body))
+    return str(p)
+
+
+def test_rank_env_matches_torchrun_contract():
+    env = launch.rank_env(3, 8, 29999, base={"FOO": "bar"})
+    assert env["RANK"] == "3" and env["LOCAL_RANK"] == "3" and env["WORLD_SIZE"] == "8" and env["LOCAL_WORLD_SIZE"] == "8"
+    assert env["MASTER_ADDR"] == "127.0.0.1" and env["MASTER_PORT"] == "29999" and env["FOO"] == "bar"
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert launch.rank_env(0, 2, 1, base={"HSA_ENABLE_IPC_MODE_LEGACY": "1"})["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"   # caller's wins
+    cmd = launch.rank_command("/x/bench.py", ["--gpus", "4", "--steps", "7"])
+    assert cmd[0] == sys.executable and cmd[-5:] == ["/x/bench.py", "--gpus", "4", "--steps", "7"]
+    with pytest.raises(ValueError):
+        launch.spawn_ranks("/x/none.py", [], 0)
+
+
+def test_spawn_relays_rank0_stdout_and_arguments(tmp_path):
+    s = _script(tmp_path, """
+        import json, os, sys
+        print(json.dumps({"rank": int(os.environ["RANK"]), "world": int(os.environ["WORLD_SIZE"]), "argv": sys.argv[1:],
+                          "port": os.environ["MASTER_PORT"]}))
+        print("note from rank " + os.environ["RANK"], file=sys.stderr)
+    """)
+    out, err = io.StringIO(), io.StringIO()
+    rc = launch.spawn_ranks(s, ["--gpus", "3", "--steps", "5"], 3, stdout=out, stderr=err)
+    assert rc == 0
+    lines = [l for l in out.getvalue().splitlines() if l.strip()]
+    assert len(lines) == 1, lines                                  # ONE line on stdout: rank 0's
+    rec = json.loads(lines[0])
+    assert rec["rank"] == 0 and rec["world"] == 3 and rec["argv"] == ["--gpus", "3", "--steps", "5"]
+    e = err.getvalue()
+    assert "[rank 1] " in e and "[rank 2] " in e and "note from rank 0" in e
+
+
+def test_spawn_propagates_failure_and_stops_other_ranks(tmp_path):
+    s = _script(tmp_path, """
+        import os, sys, time
+        if os.environ["RANK"] == "1":
+            sys.exit(7)
+        time.sleep(60)            # must be terminated by the launcher, not waited for
+    """)
+    import time
+    t0 = time.monotonic()
+    rc = launch.spawn_ranks(s, [], 2, stdout=io.StringIO(), stderr=io.StringIO())
+    assert rc == 7
+    assert time.monotonic() - t0 < 30
+
+
+def test_spawn_timeout(tmp_path):
+    s = _script(tmp_path, "import time; time.sleep(60)\n")
+    rc = launch.spawn_ranks(s, [], 2, timeout=1.0, stdout=io.StringIO(), stderr=io.StringIO())
+    assert rc != 0
+
+
+def test_two_ranks_rendezvous_over_gloo(tmp_path):
+    s = _script(tmp_path, """
+        import os, json, torch, torch.distributed as dist
+        dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+        w = torch.ones(4); dist.all_reduce(w)
+        if dist.get_rank() == 0:
+            print(json.dumps({"n_gpus": dist.get_world_size(), "counted": int(w[0])}))
+        dist.destroy_process_group()
+    """)
+    out = io.StringIO()
+    rc = launch.spawn_ranks(s, [], 2, stdout=out, stderr=io.StringIO(), timeout=120, json_only=True)
+    assert rc == 0
+    # json_only: gloo's C++ side prints its own connection notes on stdout; only the JSON line may reach ours
+    assert json.loads(out.getvalue()) == {"n_gpus": 2, "counted": 2}
+
+
+def test_bench_gpus_flag_takes_the_launcher_branch(tmp_path):
+    """`python bench.py --gpus 2` without a launcher environment must start 2 ranks (each then fails here for lack of a GPU,
+    and the parent must report that failure as a non-zero exit instead of printing an n_gpus = 1 line)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "[launch] rank" in r.stderr and "[rank 1]" in r.stderr, r.stderr[-2000:]
+    assert '"n_gpus"' not in r.stdout
+
+
+def test_bench_rejects_gpus_world_mismatch():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
