@@ -166,14 +166,23 @@ def dump_ops(path, prof):
                     f"cin={p_.get('cin', '')} cout={p_.get('cout', '')} taps={p_.get('taps', '')} pos={p_.get('positions', '')}\n")
 
 
+KIND_KERNEL = {
+    "conv3": "k_conv (3x3x3 implicit GEMM, LDS halo tile; the three Upsample convs as 2x2-tap sub-pixel phases)",
+    "conv1": "k_conv<.,1,1,1> (1x1x1 projections: skip / qkv / proj_out)",
+    "attention": "k_attn_bf16 (flash-style QK^T / PV on MFMA, fp32 online softmax)",
+}
+
+
 def roofline_of(plan, args):
-    """Dominant kernel = the 3x3x3 conv: achieved = algorithmic FLOPs of its launches in one step / their summed
-    durations, each launch bracketed by HIP events on the launch stream (plan.profile)."""
+    """Dominant kernel = the MFMA kind with the most time in one step (c3: the 3x3x3 conv; c5 with T = 32768: attention when it
+    outweighs the convs): achieved = algorithmic FLOPs of its launches in one step / their summed durations, each launch bracketed
+    by HIP events on the launch stream (plan.profile)."""
     prof = plan.profile(repeats=3)
-    conv3 = [p for p in prof if p["kind"] == "conv3"]
-    fl = sum(p["flops"] for p in conv3)
-    ms = sum(p["ms"] for p in conv3)
     kinds = by_kind(prof)
+    dom = max((k for k in ("conv3", "attention", "conv1") if k in kinds), key=lambda k: kinds[k]["ms"])
+    sel = [p for p in prof if p["kind"] == dom]
+    fl = sum(p["flops"] for p in sel)
+    ms = sum(p["ms"] for p in sel)
     if args.dump_ops:
         dump_ops(args.dump_ops, prof)
     peak = MFMA_PEAK_TFLOPS[args.dtype]
@@ -187,7 +196,7 @@ def roofline_of(plan, args):
     traffic = mfma_util = None
     traffic_note = "no PMC summary under profiles/ for this binary"
     import glob
-    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_conv3.json")))[-1:]      # names carry the round: r02b > r02a > r01h
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_traffic_{dom}.json")))[-1:]      # names carry the round: r03a > r02f
     for tpath in newest:
         with open(tpath) as f:
             tj = json.load(f)
@@ -198,22 +207,27 @@ def roofline_of(plan, args):
             traffic_note = f"{os.path.relpath(tpath, ROOT)} covers another workload"
         else:
             traffic, mfma_util = tj["hbm_bytes_per_launch"], tj.get("mfma_util")
-            traffic_note = f"{os.path.relpath(tpath, ROOT)} (build {build}; PMC FETCH_SIZE x2 + WRITE_SIZE, average per launch of the same conv3 launches)"
-    alg_bytes = sum(p["bytes"] for p in conv3)
-    # Upsample + conv runs as 2-tap sub-pixel phases (12 of the 27 taps in 3-D): `achieved` counts the ALGORITHMIC FLOPs of the
-    # reference's formulation (interpolate, then a 27-tap conv) as the contract asks; the multiply-adds the matrix cores actually
-    # execute are reported beside it
-    exe = sum(p.get("executed_flops", p["flops"]) for p in conv3)
+            traffic_note = (f"{os.path.relpath(tpath, ROOT)} (build {build}; PMC FETCH_SIZE x2 + WRITE_SIZE, average per launch of the same "
+                            f"{dom} launches)")
+    alg_bytes = sum(p["bytes"] for p in sel)
+    # Upsample + conv runs as 2-tap sub-pixel phases (12 of the 27 taps in 3-D): `achieved` / `frac` count the ALGORITHMIC FLOPs of
+    # the reference's formulation (interpolate, then a 27-tap conv) as the contract asks; `executed_frac` counts the multiply-adds
+    # the matrix cores actually execute
+    exe = sum(p.get("executed_flops", p["flops"]) for p in sel)
+    exe_tf = exe / (ms * 1e-3) / 1e12
     return {
-        "bound": "mfma", "kernel": "k_conv (3x3x3 implicit GEMM, LDS halo tile; the three Upsample convs as 2x2-tap sub-pixel phases)",
+        "bound": "mfma", "kernel": KIND_KERNEL[dom], "kind": dom,
         "achieved": achieved, "peak": peak,
-        "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_note, "mfma_util": mfma_util,
-        "build_id": build, "executed_flops_per_step": exe, "executed_TFLOPs": exe / (ms * 1e-3) / 1e12,
-        "algorithmic_bytes_per_launch": alg_bytes / max(1, len(conv3)), "algorithmic_flops_per_launch": fl / max(1, len(conv3)),
-        "launches_per_step": len(conv3), "avg_launch_ms": ms / max(1, len(conv3)),
+        "unit": "TFLOP/s", "frac": achieved / peak, "executed_frac": exe_tf / peak,
+        "traffic": traffic, "traffic_source": traffic_note, "mfma_util": mfma_util,
+        "build_id": build, "executed_flops_per_step": exe, "executed_TFLOPs": exe_tf,
+        "algorithmic_bytes_per_launch": alg_bytes / max(1, len(sel)), "algorithmic_flops_per_launch": fl / max(1, len(sel)),
+        "launches_per_step": len(sel), "avg_launch_ms": ms / max(1, len(sel)),
         "algorithmic_bytes_per_step": alg_bytes, "algorithmic_flops_per_step": fl, "kernel_ms_per_step": ms,
         "all_kernels_ms_per_step": sum(p["ms"] for p in prof),
         "by_kind_ms": {k: round(v["ms"], 3) for k, v in kinds.items()},
+        "by_kind_TFLOPs": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in kinds.items() if v["flops"] > 0 and v["ms"] > 0
+                           and k in ("conv3", "conv1", "attention")},
         "hbm_kernels_GBps": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in kinds.items()
                              if k in ("gn_partial", "pack") and v["ms"] > 0},
     }
@@ -365,9 +379,10 @@ def main():
 
     if args.mode in ("train", "both"):
         # synthetic spherical-harmonics density fields (rho_diffusion/data/synthetic.py:45-124) generated ON THE DEVICE
-        # (rho_sph_harm_fields), a pool of 8 built once before the timed region
+        # (rho_sph_harm_fields), a pool of 64 (SURVEY 8d / BASELINE.md section 3) built once before the timed region; the batch is
+        # its first B fields
         from rho_diffusion_amd.data import SphericalHarmonicPool
-        data = SphericalHarmonicPool(args.grid, args.dims, size=8, seed=777 + rank, device=device).batch(B)
+        data = SphericalHarmonicPool(args.grid, args.dims, size=64, seed=777 + rank, device=device).batch(B)
         batch = [data, labels_for(B, device)] if args.labels else data
         from rho_diffusion_amd.trainer import DPTrainer
         trainer = DPTrainer(ddpm, lr=1e-4)

@@ -34,7 +34,10 @@ extern "C" {
 #define RHO_E_ALIGN (-2)    /* pointer / channel count not aligned as required */
 #define RHO_E_SHAPE (-3)    /* tile / shape constraint violated */
 
-/* library identification: returns the ABI version (bumped on any signature change) */
+/* ABI version: bumped on ANY signature / struct-layout change (2: table_len in rho_q_sample(_coef), fmt in rho_gn_bwd_finalize,
+ * rho_conv_desc grew; 3: round-3 additions).  A loader must compare rho_abi_version() with the header it was written against
+ * before calling anything else (hip.py does; a build with all symbols but older signatures would be called with shifted arguments). */
+#define RHO_ABI_VERSION 3
 int rho_abi_version(void);
 /* static string: target arch + build flags */
 const char* rho_build_info(void);

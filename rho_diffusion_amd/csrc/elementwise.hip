@@ -10,7 +10,7 @@ static inline int grid_for(int64_t work_items, int block) {
     return (int)g;
 }
 
-extern "C" int rho_abi_version(void) { return 1; }
+extern "C" int rho_abi_version(void) { return RHO_ABI_VERSION; }
 #ifndef RHO_BUILD_ID
 #define RHO_BUILD_ID "unstamped"
 #endif

@@ -151,6 +151,22 @@ class AbstractDiffusionPipeline(_Base):
             return emb.float().contiguous()
         return cc
 
+    error_poll_every = 50
+
+    def _check_backbone_errors(self) -> None:
+        """Poll the backbone's sticky device error flag (a label outside the parameter space: IndexError like the reference's
+        conditioning.py:132).  One host sync: called where a pipeline synchronises anyway (end of a sampling chain, the
+        NaN-flag poll of DDPM.training_step), never per step."""
+        chk = getattr(self.backbone, "check_errors", None)
+        if chk is not None:
+            chk()
+
+    def _tick_error_poll(self) -> None:
+        """training_step of the pipelines without a NaN-flag poll of their own: every ``error_poll_every`` steps."""
+        self._err_ticks = getattr(self, "_err_ticks", 0) + 1
+        if self._err_ticks % self.error_poll_every == 0:
+            self._check_backbone_errors()
+
     def forward_process(self, data: Tensor, t: Union[Tensor, None] = None):
         ...
 

@@ -133,6 +133,7 @@ class DDPM(AbstractDiffusionPipeline):
                 and type(self).noise is DDPM.noise):
             done = self._reverse_process_graph(x_t, cc, engine, tables, t_dev, denoise_steps, buf, steps_per_ckpt, num_checkpoints)
             if done:
+                self._check_backbone_errors()
                 return {"buffer": buf, "denoised": x_t}
             t_dev.fill_(denoise_steps - 1)
         for t in range(denoise_steps - 1, -1, -1):
@@ -147,6 +148,7 @@ class DDPM(AbstractDiffusionPipeline):
                 buf[:, t_idx].copy_(x_t)
                 t_idx += 1
             ops.step_advance(t_dev, None, 0)
+        self._check_backbone_errors()
         return {"buffer": buf, "denoised": x_t}
 
     def _reverse_process_graph(self, x_t, cc, engine, tables, t_dev, denoise_steps, buf, steps_per_ckpt, num_checkpoints) -> bool:
@@ -210,7 +212,10 @@ class DDPM(AbstractDiffusionPipeline):
         q_sample kernel and polled every ``nan_check_every`` steps instead of syncing each step.
         Bit 0: NaN in the noised data; bit 2: a timestep outside the schedule table (IndexError in the reference)."""
         self._steps_seen += 1
-        if self._nan_flag is not None and (force or self._steps_seen % self.nan_check_every == 0):
+        due = force or self._steps_seen % self.nan_check_every == 0
+        if due:
+            self._check_backbone_errors()      # labels of the PREVIOUS steps (the flag is sticky until polled)
+        if self._nan_flag is not None and due:
             v = int(self._nan_flag.item())
             if v & 4:
                 self._nan_flag.zero_()

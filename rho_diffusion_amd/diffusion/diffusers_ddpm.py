@@ -199,6 +199,7 @@ class DiffusersDDPMPipeline(AbstractDiffusionPipeline):
                 buf[:, t_idx].copy_(x_t)
                 t_idx += 1
             ops.step_advance(t_dev, None, 0)
+        self._check_backbone_errors()
         return {"buffer": buf, "denoised": x_t}
 
     def training_step(self, batch, batch_idx: int = 0):
@@ -211,6 +212,7 @@ class DiffusersDDPMPipeline(AbstractDiffusionPipeline):
         self.data_dtype = data.dtype
         t = self.random_timesteps(data.size(0)).to(data.device)
         noisy_images, noise = self.forward_process(data, t)
+        self._tick_error_poll()
         noise_pred = self.backbone(noisy_images, t, labels) if labels is not None else self.backbone(noisy_images, t)
         ptype = self.schedule.config.prediction_type
         if ptype == "epsilon":

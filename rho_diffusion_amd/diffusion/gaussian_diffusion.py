@@ -208,6 +208,7 @@ class GaussianDiffusionPipeline(AbstractDiffusionPipeline):
                 buf[:, t_idx].copy_(x_t)
                 t_idx += 1
             ops.step_advance(t_dev, None, 0)
+        self._check_backbone_errors()
         return {"buffer": buf, "denoised": x_t}
 
     # ------------------------------------------------------------------ wrappers
@@ -247,6 +248,7 @@ class GaussianDiffusionPipeline(AbstractDiffusionPipeline):
         t = self.random_timesteps(data.size(0)).to(data.device)
         x_data, noise = self.forward_process(data, t)
         x_t = self.q_sample(x_data, t, noise=noise)
+        self._tick_error_poll()
         if labels is not None:
             out = self.backbone(x_t, t, labels)
         else:

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("RHO_HIP_LIB") or os.path.join(_HERE, "librho_hip.so")
 
 RHO_F32 = 0
 RHO_BF16 = 1
+ABI_VERSION = 3      # == RHO_ABI_VERSION of include/rho_hip.h (tests/test_cabi.py keeps the two equal)
 
 c_void_p, c_int, c_int32, c_int64, c_uint64, c_float, c_double = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
 
@@ -130,12 +131,26 @@ def load(path: str = LIB_PATH) -> C.CDLL:
             f"{path} not found: build it with `python -m rho_diffusion_amd.build` (hipcc --offload-arch=gfx950). "
             "There is no CPU/PyTorch fallback for the product path.")
     lib = C.CDLL(path)
+    check_abi(lib, path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError => ABI mismatch, fail loudly
         fn.restype = res
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def check_abi(lib: C.CDLL, path: str = "") -> None:
+    """Refuse a build whose rho_abi_version() differs from the signatures bound here (RHO_HIP_LIB / AB_REF point at arbitrary
+    builds: one with every symbol but older argument lists would be called with shifted arguments)."""
+    try:
+        fn = lib.rho_abi_version
+    except AttributeError as exc:
+        raise RhoHipError(f"{path}: no rho_abi_version symbol - not a librho_hip build") from exc
+    fn.restype, fn.argtypes = c_int, []
+    v = int(fn())
+    if v != ABI_VERSION:
+        raise RhoHipError(f"{path}: ABI version {v}, this binding was written against {ABI_VERSION} (include/rho_hip.h); rebuild it")
 
 
 def lib() -> C.CDLL:

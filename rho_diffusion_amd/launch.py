@@ -72,7 +72,14 @@ def spawn_ranks(script: str, argv: Sequence[str], nproc: int, env: Optional[Dict
     rc = 0
     t0 = time.monotonic()
     live = set(range(nproc))
+    kill_at = None                                      # once ranks were asked to stop: SIGKILL (by PID) what is left after 10 s
     while live:
+        if kill_at is None and rc != 0:
+            kill_at = time.monotonic() + 10.0
+        if kill_at is not None and time.monotonic() > kill_at:
+            for q in live:
+                procs[q].kill()
+            kill_at = float("inf")
         for r in sorted(live):
             code = procs[r].poll()
             if code is None:

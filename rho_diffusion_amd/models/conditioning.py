@@ -39,28 +39,62 @@ class MultiEmbeddings(nn.Module):
                 for key, value in embedding_size.items():
                     self.embedding_layers[key] = nn.Embedding(value, embedding_dim)
 
+    def _device_tables(self, dev):
+        """Value lists of the parameter space (float32, concatenated), their offsets and the table pointers on the device; cached
+        on the weights' storage (an optimizer arena or ``.to()`` re-homes them) like UNetEngine.cond_device_tables."""
+        keys = list(self.embedding_layers.keys())
+        weights = [self.embedding_layers[k].weight for k in keys]
+        sig = (str(dev),) + tuple(w.data_ptr() for w in weights)
+        cached = self.__dict__.get("_dev_tables")
+        if cached is None or cached["sig"] != sig:
+            vals = [torch.tensor(self.parameter_space[k]).to(torch.float32) for k in keys]    # the reference's conversion (:131)
+            off = [0]
+            for v in vals:
+                off.append(off[-1] + v.numel())
+            cached = dict(sig=sig, nkeys=len(keys), weights=weights, space=torch.cat(vals).to(dev),
+                          key_off=torch.tensor(off, dtype=torch.int32, device=dev),
+                          tables=torch.tensor([w.data_ptr() for w in weights], dtype=torch.int64, device=dev))
+            self.__dict__["_dev_tables"] = cached
+        return cached
+
     def forward(self, y: torch.Tensor) -> torch.Tensor:
         if len(self.embedding_layers) == 0:
             return None                                      # conditioning.py:117,139 (SURVEY A.3 q15)
         from .. import hip
-        from ..hip import check, ptr
         hip.require_gpu(y, "y")
-        keys = list(self.embedding_layers.keys())
-        weights = [self.embedding_layers[k].weight for k in keys]
-        dev = y.device
-        vals = [torch.tensor(self.parameter_space[k]).to(torch.float32) for k in keys]
-        off = [0]
-        for v in vals:
-            off.append(off[-1] + v.numel())
-        space = torch.cat(vals).to(dev)
-        key_off = torch.tensor(off, dtype=torch.int32, device=dev)
-        tables = torch.tensor([w.data_ptr() for w in weights], dtype=torch.int64, device=dev)
-        yf = y.to(torch.float32).contiguous()
+        tabs = self._device_tables(y.device)
+        return _MultiEmbedFunction.apply(y.to(torch.float32).contiguous(), self.embedding_dim, tabs, *tabs["weights"])
+
+
+class _MultiEmbedFunction(torch.autograd.Function):
+    """Stand-alone ``MultiEmbeddings.forward`` (callers outside the UNet engine: a user's own model, the sampling loop's
+    pre-embedding): rho_multi_embed forward, rho_multi_embed_bwd into the table gradients, so the module trains under autograd
+    like the reference's ``nn.Embedding`` sum.  An unknown label raises at once (conditioning.py:132)."""
+
+    @staticmethod
+    def forward(ctx, yf, dim, tabs, *weights):
+        from .. import hip
+        from ..hip import check, ptr
         B = yf.shape[0]
-        out = torch.empty(B, self.embedding_dim, dtype=torch.float32, device=dev)
-        err = torch.zeros(1, dtype=torch.int32, device=dev)
-        check(hip.lib().rho_multi_embed(ptr(yf), 1 if yf.dim() == 1 else yf.shape[1], ptr(space), ptr(key_off), ptr(tables), len(keys), B,
-                                        self.embedding_dim, ptr(out), None, ptr(err), hip.stream()), "rho_multi_embed")
-        if int(err.item()) & 2:                              # stand-alone call: fail as the reference does on an unknown label
+        out = torch.empty(B, dim, dtype=torch.float32, device=yf.device)
+        idx = torch.empty(B, 16, dtype=torch.int32, device=yf.device)
+        err = torch.zeros(1, dtype=torch.int32, device=yf.device)
+        check(hip.lib().rho_multi_embed(ptr(yf), 1 if yf.dim() == 1 else yf.shape[1], ptr(tabs["space"]), ptr(tabs["key_off"]),
+                                        ptr(tabs["tables"]), tabs["nkeys"], B, dim, ptr(out), ptr(idx), ptr(err), hip.stream()),
+              "rho_multi_embed")
+        if int(err.item()) & 2:
             raise IndexError("MultiEmbeddings: a label value is not in the parameter space")
+        ctx.idx, ctx.nkeys, ctx.dim = idx, tabs["nkeys"], dim
+        ctx.shapes = [tuple(w.shape) for w in weights]
         return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .. import hip
+        from ..hip import check, ptr
+        dout = dout.contiguous().float()
+        grads = [torch.zeros(s, dtype=torch.float32, device=dout.device) for s in ctx.shapes]
+        gp = torch.tensor([g.data_ptr() for g in grads], dtype=torch.int64, device=dout.device)
+        check(hip.lib().rho_multi_embed_bwd(ptr(dout), ptr(ctx.idx), ptr(gp), ctx.nkeys, dout.shape[0], ctx.dim, hip.stream()),
+              "rho_multi_embed_bwd")
+        return (None, None, None, *grads)

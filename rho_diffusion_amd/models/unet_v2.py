@@ -290,4 +290,16 @@ class UNet(nn.Module):
                 from ..autograd import UNetFunction
                 return UNetFunction.apply(x, anchor, self.engine(), timesteps, y, getattr(self, "grad_hooks", None))
         # the engine returns its (reused) output buffer; hand the caller a tensor of its own
-        return self.engine().forward(x, timesteps, y).clone()
+        out = self.engine().forward(x, timesteps, y).clone()
+        if y is not None and not torch.cuda.is_current_stream_capturing():
+            # a stand-alone inference call with labels fails like the reference's lookup (conditioning.py:132) does: at once.
+            # (the training path and the sampling loop poll the same sticky flag at their own sync points: DDPM._check_nan,
+            #  the end of reverse_process)
+            self.check_errors()
+        return out
+
+    def check_errors(self) -> None:
+        """Host poll of the device-side error flags of every engine of this model (one synchronisation per engine): raises
+        IndexError for a label value outside the parameter space (rho_multi_embed, the reference's conditioning.py:132)."""
+        for eng in self._engines.values():
+            eng.check_errors()

@@ -37,8 +37,34 @@ def test_ctypes_binding_matches_header():
     from rho_diffusion_amd import hip
     assert sorted(hip.SIGNATURES.keys()) == _declared()
     lib = hip.load()
-    assert lib.rho_abi_version() >= 1
+    header = open(os.path.join(ROOT, "include", "rho_hip.h")).read()
+    declared = int(re.search(r"#define\s+RHO_ABI_VERSION\s+(\d+)", header).group(1))
+    assert lib.rho_abi_version() == declared == hip.ABI_VERSION
     assert b"gfx950" in lib.rho_build_info()
+
+
+def test_loader_refuses_a_build_with_another_abi_version():
+    """hip.check_abi (used by hip.load and the tools/ab_*.py probes): a library reporting another version must not be bound."""
+    from rho_diffusion_amd import hip
+
+    class _Fn:
+        restype = argtypes = None
+
+        def __init__(self, v):
+            self.v = v
+
+        def __call__(self):
+            return self.v
+
+    class _Lib:
+        def __init__(self, v):
+            self.rho_abi_version = _Fn(v)
+
+    hip.check_abi(_Lib(hip.ABI_VERSION), "same")
+    with pytest.raises(hip.RhoHipError, match="ABI version"):
+        hip.check_abi(_Lib(hip.ABI_VERSION - 1), "older build")
+    with pytest.raises(hip.RhoHipError, match="rho_abi_version"):
+        hip.check_abi(object(), "not ours")
 
 
 def test_conv_desc_struct_layout():

@@ -1,0 +1,171 @@
+"""-m gpu, round 3: the device error flag of the label lookup surfaces as the reference's IndexError on every path (UNet.forward,
+training_step, graph-captured sampling); the stand-alone MultiEmbeddings trains under autograd; the BASELINE configurations c5
+(3-D 128^3 mc 32 conditioned, bf16) and c2 (2-D 128^2 mc 64 batch 64, fp32) RUN whole at full size (property checks: the full-size
+oracle is minutes of CPU, the per-layer / attention oracles at these shapes live in test_gpu_bench_shapes.py)."""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from helpers import (DEEP_GALAXY_SPACE, PARAM_SPACE, UNET_CASES, case_inputs, det_normal, det_state_dict, det_uniform, galaxy_labels,
+                     golden_template, load_golden, rel_l2)
+from gpu_util import DEV
+from oracle import ref_torch as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _cond_ddpm(T=12, dtype="fp32"):
+    from rho_diffusion_amd.diffusion import DDPM, LinearSchedule
+    from rho_diffusion_amd.models import MultiEmbeddings, UNet
+    g4 = load_golden("g4_unet.npz")
+    case = next(c for c, (_, _, yk) in UNET_CASES.items() if yk == "multi")
+    cfg, xshape, _ = UNET_CASES[case]
+    ddpm = DDPM(UNet, dict(cfg, compute_dtype=dtype), LinearSchedule(T, 1e-3, 0.02), nn.MSELoss, timesteps=T)
+    ddpm.backbone.cond_fn = MultiEmbeddings(parameter_space=PARAM_SPACE, embedding_dim=4 * cfg["model_channels"])
+    ddpm.backbone.load_state_dict(det_state_dict(golden_template(g4, case), case))
+    return ddpm.to(DEV), case, xshape
+
+
+# ----------------------------------------------------------------------------- unknown labels (engine err flag was never polled)
+def test_unknown_label_raises_from_unet_forward():
+    """conditioning.py:132: a label value outside the parameter space is an IndexError.  The engine resolves labels on the device
+    (flag bit 1); an inference call of UNet.forward polls it at once."""
+    ddpm, case, xshape = _cond_ddpm()
+    cfg, x, t, y = case_inputs(case)
+    model = ddpm.backbone.eval()
+    with torch.no_grad():
+        model(x.to(DEV), t.to(DEV), y.to(DEV))                       # good labels: fine
+        bad = y.clone().float()
+        bad[0, 0] = 123.456
+        with pytest.raises(IndexError):
+            model(x.to(DEV), t.to(DEV), bad.to(DEV))
+        model(x.to(DEV), t.to(DEV), y.to(DEV))                       # the flag was cleared by the raise
+
+
+def test_unknown_label_raises_from_training_step_at_the_poll():
+    """training_step does not sync per step (the reference's NaN check did): the sticky flag is polled every nan_check_every steps."""
+    ddpm, case, xshape = _cond_ddpm()
+    ddpm.train()
+    ddpm.nan_check_every = 3
+    cfg, x, t, y = case_inputs(case)
+    data = det_uniform(xshape, "r3data", 0, 1).to(DEV)
+    bad = y.clone().float()
+    bad[1, 0] = -77.0
+    with pytest.raises(IndexError):
+        for _ in range(4):                                            # surfaces at the latest at step 3's poll (+1: flag of the previous steps)
+            ddpm.training_step([data, bad.to(DEV)]).backward()
+    ddpm.zero_grad()
+    for _ in range(4):                                                # good labels keep training
+        ddpm.training_step([data, y.to(DEV)]).backward()
+
+
+def test_unknown_label_raises_from_graph_captured_sampling():
+    """reverse_process pre-embeds the labels once per chain (stand-alone MultiEmbeddings call: raises before the first step); labels
+    handed over already on the engine path (the conditions reach engine.forward as [B, k]) surface at the end of the chain."""
+    ddpm, case, xshape = _cond_ddpm()
+    cfg, x, t, y = case_inputs(case)
+    bad = y.clone().float()
+    bad[0, 1] = 9e9
+    with pytest.raises(IndexError):
+        ddpm.reverse_process(torch.zeros(xshape, device=DEV), conditions=bad.to(DEV))
+    # engine path: skip the pre-embedding, the captured step itself resolves the labels
+    ddpm._preembed_conditions = lambda cc: cc
+    assert ddpm.hip_graph_sampling
+    with pytest.raises(IndexError):
+        ddpm.reverse_process(torch.zeros(xshape, device=DEV), conditions=bad.to(DEV))
+    out = ddpm.reverse_process(torch.zeros(xshape, device=DEV), conditions=y.to(DEV))["denoised"]
+    assert torch.isfinite(out).all()
+
+
+def test_standalone_multi_embeddings_trains_under_autograd():
+    """MultiEmbeddings.forward outside the UNet engine: gradients reach the embedding tables like the reference's
+    nn.Embedding sum (conditioning.py:115-139), checked against stock autograd on the oracle."""
+    from rho_diffusion_amd.models import MultiEmbeddings
+    dim, B = 128, 6
+    me = MultiEmbeddings(parameter_space=DEEP_GALAXY_SPACE, embedding_dim=dim)
+    me.load_state_dict(det_state_dict(me.state_dict(), "r3me"))
+    sd = {f"cond_fn.{k}": v.clone().requires_grad_(True) for k, v in me.state_dict().items()}
+    y = torch.tensor(galaxy_labels(B), dtype=torch.float32)
+    y[3] = y[0]                                                       # a repeated row: gradients must accumulate
+    wgt = det_normal((B, dim), "r3mew")
+    (R.multi_embeddings(y, DEEP_GALAXY_SPACE, sd) * wgt).sum().backward()
+    me = me.to(DEV)
+    out = me(y.to(DEV))
+    assert out.requires_grad
+    (out * wgt.to(DEV)).sum().backward()
+    for k, layer in me.embedding_layers.items():
+        ref = sd[f"cond_fn.embedding_layers.{k}.weight"].grad
+        assert layer.weight.grad is not None, k
+        assert torch.allclose(layer.weight.grad.cpu(), ref, atol=1e-6), k
+    # the device tables are cached on the weights' storage and rebuilt when it moves
+    t1 = me._device_tables(torch.device(DEV))
+    assert me._device_tables(torch.device(DEV)) is t1
+    with torch.no_grad():
+        for layer in me.embedding_layers.values():
+            layer.weight.data = layer.weight.data.clone()
+    assert me._device_tables(torch.device(DEV)) is not t1
+    assert torch.equal(me(y.to(DEV)).detach(), out.detach())
+
+
+# ----------------------------------------------------------------------------- BASELINE configs run whole
+def _bench_unet(dims, grid, mc, dtype, labels):
+    from rho_diffusion_amd.models import MultiEmbeddings, UNet
+    torch.manual_seed(777)
+    kw = dict(data_shape=[grid] * dims, in_channels=1, out_channels=1, model_channels=mc, num_res_blocks=2, channel_mult=(1, 2, 4, 8),
+              attention_resolutions=[16, 8], num_heads=4, use_scale_shift_norm=True, dims=dims, activation="SiLU", compute_dtype=dtype)
+    if labels:
+        kw["num_classes"] = 25
+    model = UNet(**kw)
+    if labels:
+        model.cond_fn = MultiEmbeddings(parameter_space=DEEP_GALAXY_SPACE, embedding_dim=4 * mc)
+    with torch.no_grad():
+        for p in model.parameters():
+            if float(p.abs().max()) == 0.0:
+                p.normal_(0.0, 0.02)
+    return model.to(DEV).eval()
+
+
+def test_c5_whole_network_runs_at_128_cubed_conditioned():
+    """BASELINE configs[4]: 3-D 128^3, mc 32, num_classes 25 + MultiEmbeddings(128) over the DeepGalaxy space, T = 32768 attention
+    (unet_v2.py:365-436, examples/config_deep_galaxy.json).  One forward at [1, 1, 128, 128, 128]: finite, label-sensitive, and the
+    bf16 engine within 3e-2 rel-L2 of the exact-f32 engine of the same weights (the f32 engine is pinned to the reference by the
+    cond3d goldens and the 128^3 single-layer oracles)."""
+    model = _bench_unet(3, 128, 32, "bf16", True)
+    x = det_normal((1, 1, 128, 128, 128), "r3c5x").to(DEV)
+    t = torch.tensor([500], device=DEV)
+    y = torch.tensor(galaxy_labels(2), dtype=torch.float32).to(DEV)
+    with torch.no_grad():
+        p_bf = model(x, t, y[:1])
+        assert p_bf.shape == x.shape and torch.isfinite(p_bf).all()
+        p_bf2 = model(x, t, y[1:2])
+        assert float((p_bf - p_bf2).abs().max()) > 0.0                # the label reaches the output
+        model._engines.clear()
+        torch.cuda.empty_cache()
+        p_32 = model.set_compute_dtype("fp32")(x, t, y[:1])
+    assert torch.isfinite(p_32).all()
+    sl = (slice(None), slice(None), slice(40, 72))                   # a depth slab (2 M voxels)
+    e_all, e_sl = rel_l2(p_bf, p_32), rel_l2(p_bf[sl], p_32[sl])
+    assert e_all < 3e-2 and e_sl < 3e-2, (e_all, e_sl)
+
+
+def test_c2_whole_network_runs_at_full_size():
+    """BASELINE configs[1]: 2-D 128^2, mc 64, fp32 engine, batch 64: one forward; sample 5 of the batch equals the same sample run
+    alone bit for bit or to 1e-5 (per-sample GroupNorm / attention: no cross-sample coupling, layers.py:71-74), and the B = 2 head of
+    the batch matches the CPU oracle to the fp32 tolerance."""
+    model = _bench_unet(2, 128, 64, "fp32", False)
+    B = 64
+    x = det_normal((B, 1, 128, 128), "r3c2x").to(DEV)
+    t = (torch.arange(B, device=DEV) * 15) % 1000
+    with torch.no_grad():
+        p = model(x, t)
+        assert p.shape == x.shape and torch.isfinite(p).all()
+        p5 = model(x[5:6].contiguous(), t[5:6].contiguous())
+    assert rel_l2(p[5:6], p5) < 1e-5
+    torch.set_num_threads(16)
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    cfg = dict(data_shape=[128, 128], in_channels=1, out_channels=1, model_channels=64, num_res_blocks=2, channel_mult=(1, 2, 4, 8),
+               attention_resolutions=[16, 8], num_heads=4, use_scale_shift_norm=True, dims=2, activation="SiLU")
+    with torch.no_grad():
+        ref = R.unet_forward(sd, cfg, x[:2].cpu(), t[:2].cpu())
+    assert rel_l2(p[:2], ref) < 1e-4

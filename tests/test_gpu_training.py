@@ -26,6 +26,23 @@ def _build(case, dtype):
     return model
 
 
+# The suite forces the sub-pixel-phase / parity-split launches on (conftest.py: RHO_PHASE_MIN_WGS=0).  Production keeps OTHER launches
+# on small grids (c1's 2-D 64^2, small-batch 3-D below 256 workgroups): the fused-upsample forward with its dgrad + pool2x and
+# materialised-upsample wgrad, and the strided 3-D Downsample with the zero-stuffed dgrad.  "small_grid" runs the same gradient
+# goldens through exactly those (all four switches off).
+PATHS = {
+    "phased": {},
+    "small_grid": {"RHO_PHASE_UPSAMPLE": "0", "RHO_PHASE_UPSAMPLE_BWD": "0", "RHO_S2_SPLIT": "0", "RHO_S2_SPLIT_BWD": "0"},
+}
+
+
+@pytest.fixture(params=list(PATHS), ids=list(PATHS))
+def launch_path(request, monkeypatch):
+    for k, v in PATHS[request.param].items():
+        monkeypatch.setenv(k, v)
+    return request.param
+
+
 def _run_case(case, dtype):
     from rho_diffusion_amd.autograd import mse_loss
     g = load_golden("g4_unet.npz")
@@ -41,7 +58,7 @@ def _run_case(case, dtype):
 
 
 @pytest.mark.parametrize("case", list(UNET_CASES.keys()))
-def test_unet_backward_fp32_vs_reference_golden(case):
+def test_unet_backward_fp32_vs_reference_golden(case, launch_path):
     g, model, loss = _run_case(case, torch.float32)
     assert abs(loss.item() - float(g[f"{case}/loss"])) < 2e-4
     bad = []
@@ -64,7 +81,7 @@ def test_unet_backward_fp32_vs_reference_golden(case):
 
 
 @pytest.mark.parametrize("case", list(UNET_CASES.keys()))
-def test_unet_backward_bf16_tracks_reference(case):
+def test_unet_backward_bf16_tracks_reference(case, launch_path):
     """bf16 engine (c3 trains in bf16): every parameter's gradient must point where the reference's does - cosine >= 0.99
     against the oracle's full gradient vector (the oracle is pinned to the reference by the g4 digests) - and have its norm
     within 5 %; no free outliers.  Parameters whose reference gradient is numerically zero (below 1e-5 of the global gradient

@@ -10,6 +10,9 @@ from rho_diffusion_amd import hip  # noqa: F401
 dev = "cuda"
 vp = C.c_void_p
 libs = {"ref": C.CDLL(os.path.join(R0, os.environ.get("AB_REF", "tools/probe/librho_head.so"))), "new": C.CDLL(os.path.join(R0, "rho_diffusion_amd/librho_hip.so"))}
+from rho_diffusion_amd.hip import check_abi
+for _n, _l in libs.items():
+    check_abi(_l, _n)      # a probe build with older signatures would be called with shifted arguments
 for (B, T, heads, ch) in ((32, 4096, 4, 128), (2, 32768, 4, 64)):
     Cc = heads * ch
     qk = (torch.randn(B, T, 2 * Cc, device=dev) * 0.5).to(torch.bfloat16)

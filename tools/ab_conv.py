@@ -20,6 +20,9 @@ libs["tree"].rho_conv_stats_tiles.restype = C.c_int64
 libs["tree"].rho_conv_stats_tiles.argtypes = [C.c_void_p]
 for extra in os.environ.get("AB_EXTRA", "").split():
     libs[os.path.basename(extra)] = C.CDLL(os.path.join(R0, extra))
+from rho_diffusion_amd.hip import check_abi
+for _n, _l in libs.items():
+    check_abi(_l, _n)      # a probe build with older signatures would be called with shifted arguments
 cases.update({k: v + (False,) for k, v in UP.items()})
 for name, (D, H, W, cin, cout, pre) in cases.items():
     up = name in UP

@@ -14,6 +14,9 @@ cases = {"64->64 @64^3": (64, 64, 64, 64, 64), "192->64 @64^3": (64, 64, 64, 192
 libs = {"ref": C.CDLL(os.path.join(R0, os.environ.get("AB_REF", "tools/probe/librho_head.so"))), "new": C.CDLL(os.path.join(R0, "rho_diffusion_amd/librho_hip.so"))}
 for extra in os.environ.get("AB_EXTRA", "").split():          # e.g. AB_EXTRA=tools/probe/libwgrad_m16.so (timing-only probes)
     libs[os.path.basename(extra)] = C.CDLL(os.path.join(R0, extra))
+from rho_diffusion_amd.hip import check_abi
+for _n, _l in libs.items():
+    check_abi(_l, _n)      # a probe build with older signatures would be called with shifted arguments
 ZERO = os.environ.get("AB_ZERO") == "1"                       # all-zero operands: no data-dependent power draw (clock probe)
 tot = {k: 0.0 for k in libs}
 for name, (D, H, W, cin, cout) in cases.items():
