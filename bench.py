@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch the sampling step eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-checkpoint-leg", action="store_true", help="skip the short use_checkpoint=True training leg")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--dump-ops", default=None, help="write the per-launch profile (kind, shape, ms, TFLOP/s) to this file")
     ap.add_argument("--labels", action="store_true",
@@ -395,7 +396,8 @@ def main():
         dt, med = timed(train_step, tsteps, max(1, args.warmup))
         assert torch.isfinite(last["loss"]).all(), "non-finite training loss"
         results["train"] = dict(dt=dt, steps=tsteps, loss=float(last["loss"].detach()), median_ms=med,
-                                peak_mem_gb=round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1))
+                                peak_mem_gb=round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
+                                plan_gb=round(engine._last_train_plan.nbytes() / 2 ** 30, 1))
         if rank == 0 and not args.no_roofline:
             tp = engine._last_train_plan
             bprof = tp.profile(repeats=1, backward=True)
@@ -423,6 +425,30 @@ def main():
                                                             if v["flops"] > 0 and v["ms"] > 0}}
             if roofline is None:
                 roofline = roofline_of(tp, args)
+            del tp, bprof
+        if not args.no_checkpoint_leg:
+            # the same step with use_checkpoint=True on every ResBlock (reference: layers.py:153-199, unet_v2.py:266-271): activated
+            # conv inputs are re-materialised in backward instead of kept.  Reported beside the main training rate, never as `value`.
+            from rho_diffusion_amd.models.unet_v2 import ResBlock
+            for m_ in ddpm.backbone.modules():
+                if isinstance(m_, ResBlock):
+                    m_.use_checkpoint = True
+            engine._plans = {k_: v_ for k_, v_ in engine._plans.items() if not k_[2]}       # drop the training plans: rebuilt with the flag
+            engine._last_train_plan = None
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            torch.cuda.reset_peak_memory_stats(device)
+            dtc_, medc_ = timed(train_step, min(3, tsteps), 1)
+            nst_ = min(3, tsteps)
+            results["train"]["use_checkpoint"] = {
+                "samples_per_sec": world * B * nst_ / dtc_, "ms_per_step": 1e3 * dtc_ / nst_, "steps": nst_,
+                "peak_mem_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
+                "plan_gb": round(engine._last_train_plan.nbytes() / 2 ** 30, 1),
+                "what": "every ResBlock built with use_checkpoint=True: GroupNorm+FiLM+SiLU outputs recomputed in backward, not kept"}
+            for m_ in ddpm.backbone.modules():
+                if isinstance(m_, ResBlock):
+                    m_.use_checkpoint = False
 
     if "sample" in results or "ddim" in results:
         r = results["sample"] if "sample" in results else results["ddim"]
@@ -458,11 +484,13 @@ def main():
         out["training"] = {"metric": "training_samples_per_sec", "value": world * B * r["steps"] / r["dt"], "unit": "samples/s",
                            "steps": r["steps"], "ms_per_step": 1e3 * r["dt"] / r["steps"], "ms_per_step_hipevent_median": r["median_ms"],
                            "loss": r["loss"],
-                           "peak_mem_gb": r.get("peak_mem_gb"),
+                           "peak_mem_gb": r.get("peak_mem_gb"), "plan_gb": r.get("plan_gb"),
                            "step": "q_sample + UNetv2 fwd + MSE + bwd + " + ("RCCL grad all-reduce + " if world > 1 else "") + "fused AdamW"}
 
     if roofline is not None:
         out["roofline"] = roofline
+    if "train" in results and results["train"].get("use_checkpoint"):
+        out["training"]["use_checkpoint"] = results["train"]["use_checkpoint"]
     if "train" in results and results["train"].get("breakdown"):
         out["training"]["by_kind_ms"] = results["train"]["breakdown"]
         out["training"]["roofline"] = results["train"]["roofline"]

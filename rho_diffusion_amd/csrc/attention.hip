@@ -14,6 +14,8 @@
 //   O^T[c][query] += V^T[c][key] * P^T[key][query]
 // with V^T read as plain 16-byte rows of 8 consecutive keys (A operand) -- no transposes, no LDS
 // round trip for P (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's operand").
+#include <cstdlib>
+
 #include "common.h"
 
 template <int CH, int KT>  // KT keys per LDS tile (64; 32 for CH = 256 to stay inside static LDS)
@@ -303,6 +305,155 @@ __global__ __launch_bounds__(256) void k_attn_f32(const float* __restrict__ qk, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Exact-fp32 on the matrix cores (round 3): the same flash structure as k_attn_bf16 on v_mfma_f32_32x32x2_f32 (f32 in, f32
+// accumulate: bitwise an fmaf chain per output, 64 FLOP / clk / SIMD = the f32 vector peak, MI355X_MICROARCH.md) - the VALU
+// variant above spends its time on LDS-fed scalar FMAs and shuffles (c2, T = 256, ch = 128: 1.3 ms per block for 8.6 GFLOP).
+//   S^T[key][q]  = K * Q^T : A = K[key = lane & 31][2 channels, one per half-wave], B = Q in registers.  Any pairing of channels
+//                            into k-steps is valid as long as A and B agree: half 0 walks channels 0 .. CH/2-1, half 1 the other
+//                            half, so both read whole float4 pieces (four k-steps per ds_read_b128).
+//   O^T[c][q]   += V^T[c][key] * P^T[key][q] : accumulator register r of S^T holds key (r & 3) + 8 (r >> 2) + 4 half of the lane's
+//                            query - exactly the two rows k-step r of the next MFMA contracts, so P never leaves its registers
+//                            and is not rounded (the bf16 kernel rounds P to bf16 here); A = V^T rows read as float4 of 4 keys.
+template <int CH, int KT>
+__global__ __launch_bounds__(256) void k_attn_f32m(const float* __restrict__ qk, const float* __restrict__ vt, float* __restrict__ out,
+                                                   int T, int C, float scale_log2e, float* __restrict__ lse) {
+    constexpr int KP = CH * 4 + 16;      // K tile row pitch in bytes: odd number of 16-byte slots
+    constexpr int VP = KT * 4 + 16;      // V^T tile row pitch
+    constexpr int NJ = CH / 8;           // float4 pieces per half-wave of one K / Q row
+    constexpr int NCT = (CH + 31) / 32;
+    constexpr int NU = KT / 32;
+    static_assert(CH % 8 == 0 && KT % 32 == 0, "tile shape");
+    __shared__ __attribute__((aligned(16))) char k_lds[KT * KP];
+    __shared__ __attribute__((aligned(16))) char v_lds[NCT * 32 * VP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int qi = blockIdx.x * 128 + wave * 32 + col;
+    const size_t row2c = (size_t)2 * C;
+
+    float4 qf[NJ];
+    {
+        const int qc = qi < T ? qi : T - 1;
+        const float* qp = qk + ((size_t)b * T + qc) * row2c + (size_t)h * CH + half * (CH / 2);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) qf[j] = *reinterpret_cast<const float4*>(qp + 4 * j);
+    }
+    f32x16_t o[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ct][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+    const float sc = scale_log2e;
+    const bool vec_v = ((T & 3) == 0);
+    constexpr int KPC = CH / 4;           // float4 pieces per K row
+    constexpr int VPC = KT / 4;           // float4 pieces per V^T row
+    const float* const kbase = qk + (size_t)b * T * row2c + C + (size_t)h * CH;
+    const float* const vbase = vt + ((size_t)b * C + (size_t)h * CH) * T;
+
+    for (int kt0 = 0; kt0 < T; kt0 += KT) {
+        __syncthreads();                  // the previous tile's fragments are consumed
+        for (int pc = tid; pc < KT * KPC; pc += 256) {
+            const int key = pc / KPC, piece = pc % KPC;
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (kt0 + key < T) v = *reinterpret_cast<const float4*>(kbase + (size_t)(kt0 + key) * row2c + piece * 4);
+            *reinterpret_cast<float4*>(k_lds + key * KP + piece * 16) = v;
+        }
+        if (vec_v) {
+            for (int pc = tid; pc < NCT * 32 * VPC; pc += 256) {
+                const int c = pc / VPC, piece = pc % VPC;
+                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (c < CH && kt0 + piece * 4 < T) v = *reinterpret_cast<const float4*>(vbase + (size_t)c * T + kt0 + piece * 4);
+                *reinterpret_cast<float4*>(v_lds + c * VP + piece * 16) = v;
+            }
+        } else {                          // T not a multiple of 4 (tiny test shapes)
+            for (int e = tid; e < NCT * 32 * KT; e += 256) {
+                const int c = e / KT, key = e % KT;
+                *reinterpret_cast<float*>(v_lds + c * VP + key * 4) = (c < CH && kt0 + key < T) ? vbase[(size_t)c * T + kt0 + key] : 0.0f;
+            }
+        }
+        __syncthreads();
+
+        f32x16_t s[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[u][r] = 0.0f;
+            const char* kp = k_lds + (32 * u + col) * KP + half * (CH / 2) * 4;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float4 a = *reinterpret_cast<const float4*>(kp + 16 * j);
+                s[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qf[j].x, s[u], 0, 0, 0);
+                s[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qf[j].y, s[u], 0, 0, 0);
+                s[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qf[j].z, s[u], 0, 0, 0);
+                s[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qf[j].w, s[u], 0, 0, 0);
+            }
+        }
+        if (kt0 + KT > T) {               // partial last tile: mask the keys beyond T (uniform branch)
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kt0 + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * half >= T) s[u][r] = -INFINITY;
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[u][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx * sc);
+        if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+            const float alpha = exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+            m_run = m_new;
+        }
+        float ps = 0.0f;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = exp2f(fmaf(s[u][r], sc, -m_run));
+                s[u][r] = pv;
+                ps += pv;
+            }
+        ps += __shfl_xor(ps, 32, 64);
+        l_run += ps;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const char* vp = v_lds + (32 * ct + col) * VP + (32 * u + 4 * half) * 4;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 a = *reinterpret_cast<const float4*>(vp + 32 * g);        // keys 32u + 8g + 4 half + {0..3}
+                    o[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, s[u][4 * g + 0], o[ct], 0, 0, 0);
+                    o[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, s[u][4 * g + 1], o[ct], 0, 0, 0);
+                    o[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, s[u][4 * g + 2], o[ct], 0, 0, 0);
+                    o[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, s[u][4 * g + 3], o[ct], 0, 0, 0);
+                }
+            }
+    }
+    if (qi < T) {
+        const float inv = 1.0f / l_run;
+        if (lse != nullptr && half == 0) lse[((size_t)b * gridDim.y + h) * T + qi] = m_run + log2f(l_run);
+        float* op = out + ((size_t)b * T + qi) * C + (size_t)h * CH;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int c = 32 * ct + 8 * rg + 4 * half;
+                if (c < CH)
+                    *reinterpret_cast<float4*>(op + c) = make_float4(o[ct][4 * rg + 0] * inv, o[ct][4 * rg + 1] * inv,
+                                                                     o[ct][4 * rg + 2] * inv, o[ct][4 * rg + 3] * inv);
+            }
+    }
+}
+
 extern "C" int rho_attention_fwd(const void* qk, const void* vt, void* out, float* lse, int dtype, int64_t batch, int64_t t,
                                  int64_t heads, int64_t ch, void* stream) {
     if (!qk || !vt || !out || batch <= 0 || t <= 0 || heads <= 0) return RHO_E_ARG;
@@ -311,6 +462,28 @@ extern "C" int rho_attention_fwd(const void* qk, const void* vt, void* out, floa
     const float sl2 = (float)(1.4426950408889634 / sqrt((double)ch));
     hipStream_t st = as_stream(stream);
     if (dtype == RHO_F32) {
+        // exact-f32 MFMA kernel (RHO_ATTN_F32_VALU=1 selects the round-1 VALU kernel: A/B and cross-check)
+        static const bool valu_env = getenv("RHO_ATTN_F32_VALU") && atoi(getenv("RHO_ATTN_F32_VALU")) != 0;
+        if (!valu_env) {
+            dim3 grid((unsigned)((t + 127) / 128), (unsigned)heads, (unsigned)batch), block(256);
+#define RHO_ATT32M(chv, ktv)                                                                                             \
+    case chv:                                                                                                            \
+        hipLaunchKernelGGL((k_attn_f32m<chv, ktv>), grid, block, 0, st, (const float*)qk, (const float*)vt, (float*)out, \
+                           (int)t, C, sl2, lse);                                                                         \
+        break;
+            switch (ch) {
+                RHO_ATT32M(16, 64)
+                RHO_ATT32M(32, 64)
+                RHO_ATT32M(64, 64)
+                RHO_ATT32M(128, 32)
+                RHO_ATT32M(256, 32)
+                default:
+                    return RHO_E_SHAPE;
+            }
+#undef RHO_ATT32M
+            RHO_LAUNCH_CHECK();
+            return 0;
+        }
         dim3 grid((unsigned)((t + 63) / 64), (unsigned)heads, (unsigned)batch), block(256);
 #define RHO_ATT32(chv, ktv)                                                                                             \
     case chv:                                                                                                           \

@@ -454,6 +454,16 @@ class _Plan:
             self.keep.append(t)
             return t
 
+        scratch_of: Dict[tuple, Tensor] = {}
+
+        def scratch(*shape, dtype=dt):
+            """A buffer that is dead once the launch after its producer has run (the materialised activated input of ONE conv):
+            shared by every request of the same size - launches of a plan are stream-ordered, also inside a captured graph."""
+            key = (int(torch.Size(shape).numel()), dtype)
+            if key not in scratch_of:
+                scratch_of[key] = buf(key[0], dtype=dtype)
+            return scratch_of[key].view(*shape)
+
         # ---- embedding chain: table gather -> Linear -> (SiLU) Linear (+cond) -> (SiLU) batched FiLM GEMV
         self.t_in = buf(B, dtype=torch.int64)
         self.sin_in = buf(B, eng.mc, dtype=torch.float32)
@@ -522,7 +532,7 @@ class _Plan:
             return dict(x1=x1, x2=x2, norm=norm, film_off=off, a=a, b=b, st=st, part=part, N=N, S=S, C=Cc, nblk=nblk)
 
         def conv(x1, x2, cw, *, stride_hw=(1, 1), up_hw=(0, 0), pre=None, pre_silu=False, res=None, res_add_off=None,
-                 split=None, y2_dtype=None, stem=False, want_stats=True):
+                 split=None, y2_dtype=None, stem=False, want_stats=True, ckpt=False):
             cout = cw.cout
             split_ = cout if split is None else split
             N, Do, Ho, Wo = ops.conv_out_shape(x1.shape, cw.kernel, stride_hw, up_hw)
@@ -537,13 +547,18 @@ class _Plan:
             # halo tile it stages (2.5x the input per tile): 8.5 % of the launch against a 0.05 ms pass that applies it once
             # (tools/ab_conv.py, "+pre" rows; only where the tensor is small enough that the extra pass costs less than the prologue)
             wide_3x3 = (cw.taps > 1 and cout >= self.materialize_min_cout and dt == torch.bfloat16)
-            if pre is not None and up_hw == (0, 0) and ((self.train and self.materialize_act) or wide_1x1 or wide_3x3):
+            # ``ckpt`` (a ResBlock built with use_checkpoint=True; reference: layers.py:153-199 re-runs the block in backward instead of
+            # keeping its intermediates): the activated inputs of the block's convs are NOT kept - backward re-materialises them
+            # into a recycled buffer (the recompute path of bias_and_wgrad), the forward conv applies GroupNorm + FiLM + SiLU in its
+            # loader or, for the wide layers, from a scratch copy that the next conv overwrites
+            keep_act = self.train and self.materialize_act and not ckpt
+            if pre is not None and up_hw == (0, 0) and (keep_act or wide_1x1 or wide_3x3):
                 # training: the activated input act(a*x+b) is needed twice (this conv, its weight gradient) and the conv
                 # loader would recompute it 2.3x (halo) per cout tile: materialise it once (one HBM-rate pass, kept for
                 # backward: +1 activation-sized buffer per normalised conv, 38 GB at c3) and feed both from it
                 c1_ = x1.shape[-1]
                 c2_ = x2.shape[-1] if x2 is not None else 0
-                xact = buf(*x1.shape[:4], c1_ + c2_)
+                xact = (buf if keep_act else scratch)(*x1.shape[:4], c1_ + c2_)
                 Sx = x1.shape[1] * x1.shape[2] * x1.shape[3]
                 ga = (ptr(x1), c1_, ptr(x2), c2_, dtc, x1.shape[0], Sx, ptr(pre["a"]), ptr(pre["b"]), int(pre_silu), ptr(xact))
                 self.ops.append(lambda s, a=ga: L.rho_gn_apply(*a, s))
@@ -606,7 +621,7 @@ class _Plan:
                                         + taps_run * cout * cw.cin)))
             self.nodes.append(dict(k="conv", cw=cw, x1=x1, x2=x2, y=y, y2=y2, stride_hw=stride_hw, up_hw=up_hw, pre=pre,
                                    pre_silu=pre_silu, res=res, res_add_off=res_add_off, stem=stem, out_dims=(N, Do, Ho, Wo),
-                                   xact=xact, phased=phased, s2=s2))
+                                   xact=xact if keep_act else None, phased=phased, s2=s2))
             return y, y2
 
         rs_hw = (1, 1) if dims >= 2 else (0, 1)      # axes a Down/Upsample touches: H and W (3-D: depth stays), 1-D: W only
@@ -655,7 +670,7 @@ class _Plan:
                 sk = x1p
             else:
                 sk, _ = conv(x1p, x2p, eng._conv(blk.skip_connection))
-            out, _ = conv(t1, None, eng._conv(blk.out_layers[3]), pre=g2, pre_silu=True, res=sk)
+            out, _ = conv(t1, None, eng._conv(blk.out_layers[3]), pre=g2, pre_silu=True, res=sk, ckpt=bool(blk.use_checkpoint))
             return out
 
         def resblock(blk, h1, h2):
@@ -663,14 +678,15 @@ class _Plan:
                 return resblock_updown(blk, h1, h2)
             g1 = gn(h1, h2, blk.in_layers[0])
             radd = None if blk.use_scale_shift_norm else eng._film_off[id(blk)]
-            t1, _ = conv(h1, h2, eng._conv(blk.in_layers[2]), pre=g1, pre_silu=True, res_add_off=radd)
+            ck = bool(blk.use_checkpoint)
+            t1, _ = conv(h1, h2, eng._conv(blk.in_layers[2]), pre=g1, pre_silu=True, res_add_off=radd, ckpt=ck)
             g2 = gn(t1, None, blk.out_layers[0], film_blk=blk if blk.use_scale_shift_norm else None)
             if isinstance(blk.skip_connection, nn.Identity):
                 assert h2 is None
                 sk = h1
             else:
                 sk, _ = conv(h1, h2, eng._conv(blk.skip_connection))
-            out, _ = conv(t1, None, eng._conv(blk.out_layers[3]), pre=g2, pre_silu=True, res=sk)
+            out, _ = conv(t1, None, eng._conv(blk.out_layers[3]), pre=g2, pre_silu=True, res=sk, ckpt=ck)
             return out
 
         def attention(blk, xin):
@@ -1108,6 +1124,15 @@ class _Plan:
         emb_params += [te2.weight, te2.bias, te0.weight, te0.bias]
         self.bwd_marks.append((len(bw), emb_params))
         self.pool_bytes = sum(t.numel() * t.element_size() for t in pool.all)
+
+    def nbytes(self) -> int:
+        """Device bytes this plan owns (forward buffers kept for its lifetime + the backward pool)."""
+        seen, tot = set(), 0
+        for t in self.keep:
+            if torch.is_tensor(t) and t.data_ptr() not in seen:
+                seen.add(t.data_ptr())
+                tot += t.numel() * t.element_size()
+        return tot + int(getattr(self, "pool_bytes", 0))
 
     def variants(self) -> List[str]:
         """Names of the k_conv / k_wgrad instantiations this plan launches (rho_conv_variant / rho_conv_wgrad_variant)."""

@@ -15,7 +15,7 @@ from oracle import ref_torch as R
 pytestmark = pytest.mark.gpu
 
 
-def _cond_ddpm(T=12, dtype="fp32"):
+def _cond_ddpm(T=50, dtype="fp32"):      # (LinearSchedule scales beta by 1000 / T: below T = 20 beta_T exceeds 1 and q_sample is NaN)
     from rho_diffusion_amd.diffusion import DDPM, LinearSchedule
     from rho_diffusion_amd.models import MultiEmbeddings, UNet
     g4 = load_golden("g4_unet.npz")
@@ -169,3 +169,38 @@ def test_c2_whole_network_runs_at_full_size():
     with torch.no_grad():
         ref = R.unet_forward(sd, cfg, x[:2].cpu(), t[:2].cpu())
     assert rel_l2(p[:2], ref) < 1e-4
+
+
+# ----------------------------------------------------------------------------- use_checkpoint (layers.py:153-199, unet_v2.py:266-271)
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", ["tiny3d", "tiny2d"])
+def test_use_checkpoint_recomputes_in_backward_same_gradients_less_memory(case, dtype):
+    """use_checkpoint=True trades the kept intermediates of every ResBlock for recomputation in backward, with identical results
+    (the reference's CheckpointFunction re-runs the block).  Here: the activated conv inputs act(GroupNorm(x) * (1 + scale) + shift)
+    are not kept but re-materialised by backward - same kernels on the same values, so the loss is bit-identical and every gradient
+    equal up to the summation order of the weight-gradient kernel's fp32 atomics (1e-5 relative: the run-to-run noise of one plan),
+    and the plan must own fewer bytes."""
+    from rho_diffusion_amd.autograd import mse_loss
+    from rho_diffusion_amd.models import UNet
+    if case not in UNET_CASES:
+        pytest.skip(f"no golden case {case}")
+    g = load_golden("g4_unet.npz")
+    kw, xshape, ykind = UNET_CASES[case]
+    assert ykind is None
+    cfg, x, t, _ = case_inputs(case)
+    res = {}
+    for ck in (False, True):
+        model = UNet(**dict(kw, use_checkpoint=ck), compute_dtype=dtype)
+        model.load_state_dict(det_state_dict(golden_template(g, case), case))
+        model = model.to(DEV).train()
+        assert all(b.use_checkpoint == ck for b in model.modules() if type(b).__name__ == "ResBlock")
+        pred = model(x.to(DEV), t.to(DEV))
+        loss = mse_loss(pred, det_normal(tuple(pred.shape), case + "tgt").to(DEV))
+        loss.backward()
+        plan = model.engine()._last_train_plan
+        res[ck] = (float(loss), {n: p.grad.clone() for n, p in model.named_parameters()}, plan.nbytes())
+    assert res[True][0] == res[False][0]
+    for n, gr in res[False][1].items():
+        d = float((res[True][1][n].double() - gr.double()).norm())
+        assert d <= 1e-5 * float(gr.double().norm()) + 1e-9, (n, d)
+    assert res[True][2] < 0.8 * res[False][2], (res[True][2], res[False][2])
