@@ -89,11 +89,17 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     constexpr int CK = ET<T>::CK;
     constexpr int PE = ET<T>::PE;
     constexpr int NT = KD * KH * KW;
-    constexpr bool TAPSPLIT = NT >= 9;               // taps dealt to waves; else positions dealt to waves
+    constexpr bool IS_BF16 = sizeof(T) == 2;
+    // taps dealt to waves; else positions dealt to waves.  (f32, 9 taps: positions - dealing 9 taps to 4 waves leaves one wave idle,
+    // and the f32 accumulators of all 9 taps fit one wave: 5 tap-pair tiles of 16 registers, see F32 below)
+    constexpr bool TAPSPLIT = IS_BF16 ? (NT >= 9) : (NT > 9);
     constexpr int TPW = TAPSPLIT ? (NT + 3) / 4 : NT;  // taps per wave
     constexpr int COT = 128 / (int)sizeof(T);        // cout tile: 64 bf16 / 32 f32
     constexpr int MT = COT / 32;
-    constexpr bool IS_BF16 = sizeof(T) == 2;
+    // exact f32 (v_mfma_f32_32x32x2_f32): a 64-byte chunk is 16 input channels, half the 32 columns of the MFMA's B operand.
+    // Round 3: the other 16 columns carry the SAME channels at the wave's NEXT tap (a per-lane tap offset), so one MFMA reduces
+    // two taps (r02 fed them zeros: c2's weight gradient ran at 0.18 of the f32 matrix peak, 184 of 314 ms per training step).
+    constexpr int NACC = IS_BF16 ? TPW : (TPW + 1) / 2;
     constexpr int NKS = TAPSPLIT ? 16 : 4;           // 16-position k-steps of this wave per tile
     constexpr bool KEEP_REL = (MAXP <= 10);          // big-halo (strided) variant recomputes instead of holding registers
     // PIPE (bf16, regular halo): the LDS tiles are DOUBLE-BUFFERED (2 x (40 KB halo + 32 KB dY) = 144 of the 160 KB) and the staging
@@ -178,9 +184,9 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
         tapoff[ti] = ((kd * p.IH + kh) * p.IW + kw) * XP;
     }
 
-    f32x16_t acc[TPW][MT];
+    f32x16_t acc[NACC][MT];
 #pragma unroll
-    for (int ti = 0; ti < TPW; ++ti)
+    for (int ti = 0; ti < NACC; ++ti)
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -495,20 +501,24 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
                     for (int j = 0; j < NKS; ++j) kstep(j, xrow_of(j, 0), xrow_of(j, 1));   // rolled: keeps the decode out of registers
                 }
             } else {
-                // exact f32: k = position pair (2*kk + half); lanes with ci >= 16 contribute zeros
+                // exact f32: k = position pair (2*kk + half); columns 0-15 = the 16 channels at tap 2s, columns 16-31 = the same
+                // channels at tap 2s + 1 of this wave (an odd tap count leaves the last slot's upper half on a repeat that is not flushed)
                 const int kk0 = TAPSPLIT ? 0 : wave * 32;
                 const int kk1 = TAPSPLIT ? 128 : wave * 32 + 32;
                 const int col = lane & 31;
+                int toff2[NACC];
+    #pragma unroll
+                for (int s_ = 0; s_ < NACC; ++s_)
+                    toff2[s_] = ((col >= 16 && 2 * s_ + 1 < TPW) ? tapoff[(2 * s_ + 1 < TPW) ? 2 * s_ + 1 : 0] : tapoff[2 * s_]) + (col & 15) * 4;
                 for (int kk = kk0; kk < kk1; ++kk) {
                     const int pp = 2 * kk + half;
                     const int pw = pp & (p.TW - 1), ph = (pp >> p.lgTW) & (p.TH - 1), pd = pp >> (p.lgTW + p.lgTH);
                     const float av = *reinterpret_cast<const float*>(dyt + pp * DYP + ((col * 4) ^ dy_swz(pp)));
-                    const int xr = ((pd * p.IH + ph * p.sh) * p.IW + pw * p.sw) * XP + (col & 15) * 4;
+                    const int xr = ((pd * p.IH + ph * p.sh) * p.IW + pw * p.sw) * XP;
     #pragma unroll
-                    for (int ti = 0; ti < TPW; ++ti) {
-                        float bv = *reinterpret_cast<const float*>(halo + xr + tapoff[ti]);
-                        bv = (col < 16) ? bv : 0.0f;
-                        acc[ti][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[ti][0], 0, 0, 0);
+                    for (int s_ = 0; s_ < NACC; ++s_) {
+                        const float bv = *reinterpret_cast<const float*>(halo + xr + toff2[s_]);
+                        acc[s_][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[s_][0], 0, 0, 0);
                     }
                 }
             }
@@ -536,18 +546,34 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     }
 
     // ---- flush: lane holds ci = c + (lane&31), rows co0 + 32*mi + (r&3) + 8*(r>>2) + 4*half
-    const int ci = c + (lane & 31);
-    const bool ci_ok = IS_BF16 ? true : ((lane & 31) < 16);
+    if constexpr (IS_BF16) {
+        const int ci = c + (lane & 31);
 #pragma unroll
-    for (int ti = 0; ti < TPW; ++ti) {
-        if (tap_of[ti] < NT && ci_ok) {
+        for (int ti = 0; ti < TPW; ++ti) {
+            if (tap_of[ti] < NT) {
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = co0 + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (co < p.coutp) atomicAdd(p.dw + ((size_t)tap_of[ti] * p.coutp + co) * p.cin + ci, acc[ti][mi][r]);
+                    }
+            }
+        }
+    } else {
+        // f32: lane column (lane & 31) = channel c + (column & 15) at tap 2s (columns 0-15) / 2s + 1 (columns 16-31)
+        const int ci = c + (lane & 15);
+        const bool upper = (lane & 31) >= 16;
+#pragma unroll
+        for (int s_ = 0; s_ < NACC; ++s_) {
+            const int tap = upper ? ((2 * s_ + 1 < TPW) ? tap_of[(2 * s_ + 1 < TPW) ? 2 * s_ + 1 : 0] : NT) : tap_of[2 * s_];
+            if (tap < NT) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int co = co0 + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (co < p.coutp) atomicAdd(p.dw + ((size_t)tap_of[ti] * p.coutp + co) * p.cin + ci, acc[ti][mi][r]);
+                    const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (co < p.coutp) atomicAdd(p.dw + ((size_t)tap * p.coutp + co) * p.cin + ci, acc[s_][0][r]);
                 }
+            }
         }
     }
 }

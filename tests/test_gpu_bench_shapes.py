@@ -78,6 +78,7 @@ LAYER_CASES = [
 ]
 _IDS = [c[0] for c in LAYER_CASES]
 _SEEN = {}          # case name -> set of variant names its launches used (filled by the parity test)
+_SPLIT_ERR = {}     # case name -> (single-launch fwd error, parity-split fwd error, parity-split dgrad error) vs the fp32 oracle
 
 
 def _geom(dims, k, stride, up):
@@ -223,6 +224,13 @@ def _run_layer(ops, case, check=True):
         if check:
             assert rel_l2(from_cl(ys, dims), ref) < tol_f, f"fwd parity split {name}"
             assert rel_l2(from_cl(dxs, dims), gx) < tol_b, f"dgrad parity split {name}"
+            # the four parity launches accumulate in place through the bf16 output (up to four roundings where the
+            # single strided launch rounds once).  Quantified against the same fp32 oracle: the split's error may not exceed the
+            # single launch's by more than a quarter (+1e-4); DESIGN.md section 4 quotes the measured pairs.
+            e_single, e_split = rel_l2(from_cl(y, dims), ref), rel_l2(from_cl(ys, dims), ref)
+            _SPLIT_ERR[name] = (e_single, e_split, rel_l2(from_cl(dxs, dims), gx))
+            print(f"[split-rounding] {name}: fwd single {e_single:.3e} split {e_split:.3e}; dgrad split {_SPLIT_ERR[name][2]:.3e}")
+            assert e_split <= 1.25 * e_single + 1e-4, f"parity split rounding {name}: {e_split:.3e} vs single launch {e_single:.3e}"
 
     # ---------------- data gradient (w.r.t. the activated input; the GroupNorm backward is a separate kernel)
     ck = 32 if dtype == BF16 else 16
@@ -248,6 +256,9 @@ def _run_layer(ops, case, check=True):
         if check:
             ops.conv_launch(dd)
             gotx = from_cl(y_, dims)
+            if name in _SPLIT_ERR:       # parity-split data gradient vs the single zero-stuffed launch, same oracle
+                e1 = rel_l2(gotx, gx)
+                assert _SPLIT_ERR[name][2] <= 1.25 * e1 + 1e-4, f"parity split dgrad rounding {name}: {_SPLIT_ERR[name][2]:.3e} vs {e1:.3e}"
     elif c2 and pre is None:
         # un-normalised concatenated input (the 1x1 skip of an output-side ResBlock): two channels-last gradients
         y_ = torch.empty(N, Din, Hin, Win, c1, dtype=dtype, device=DEV)
