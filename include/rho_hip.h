@@ -429,6 +429,26 @@ int rho_attention_bwd(const void* qk, const void* vt, const void* o, const void*
                       float* delta_ws, void* dqk, int64_t dqk_row_stride, void* dv, int64_t dv_row_stride, int dtype,
                       int64_t batch, int64_t t, int64_t heads, int64_t ch, void* stream);
 
+/* ------------------------------------------------------------------ legacy UNet ("UNet v1", rho_diffusion/models/unet.py:30-269)
+ * The tail of AbstractUNetBlock.forward (unet.py:117-135) on channels-last [N, S, C] tensors of `dtype`:
+ *     h = act(conv2(act(conv1 x))) + residual_conv(x) + time_pe[n, c];   out = act(GroupNorm(groups, C)(h)).
+ * act: 0 identity, 1 SiLU, 2 ReLU, 3 GELU (erf form, the nn.GELU() default the registry resolves "GELU" to). */
+
+/* out = act(x) + r + nc[n, c]   (r and nc optional): unet.py:121-129 after the two convolutions. */
+int rho_act_add(const void* x, const void* r, const float* nc, void* out, int dtype, int64_t n, int64_t s, int64_t c, int act,
+                void* stream);
+/* dx = dout * act'(x): autograd of the activation in front of the add. */
+int rho_act_bwd(const void* x, const void* dout, void* dx, int dtype, int64_t numel, int act, void* stream);
+/* y = act(GroupNorm(groups, C, eps)(x) * gamma + beta), nn.GroupNorm semantics (biased variance) for ANY group count
+ * (unet.py:109-112 builds GroupNorm(8, C); the UNetv2 kernels are specialised for GroupNorm32); stats [N, groups, 2] =
+ * (mean, rstd) is written for the backward. */
+int rho_groupnorm_act(const void* x, void* y, float* stats, const float* gamma, const float* beta, int dtype, int64_t n, int64_t s,
+                      int64_t c, int64_t groups, float eps, int act, void* stream);
+/* its backward: dx, and dgamma[c] / dbeta[c] ACCUMULATED (fp32 atomics over samples: zero them first). */
+int rho_groupnorm_act_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta, void* dx,
+                          float* dgamma, float* dbeta, int dtype, int64_t n, int64_t s, int64_t c, int64_t groups, int act,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

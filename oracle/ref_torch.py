@@ -596,3 +596,40 @@ def spherical_harmonic_field(l: int, m: int, grid: int, dims: int = 3):
     if dims == 2:
         out = out[:, :, grid // 2]
     return torch.from_numpy(out)[None]
+
+
+# --------------------------------------------------------------------------- legacy UNet ("UNet v1")
+_V1_ACT = {"ReLU": F.relu, "GELU": F.gelu, "SiLU": F.silu, "Identity": lambda v: v}
+
+
+def unet_v1_block(x: Tensor, time_pe: Tensor, sd: Dict[str, Tensor], p: str, is_up: bool, act, groups: int = 8) -> Tensor:
+    """AbstractUNetBlock.forward, rho_diffusion/models/unet.py:117-135 (2-D): two 3x3 convolutions with the activation after each,
+    + residual_conv(x) when present, + the time embedding read out per channel, GroupNorm(groups), activation.  'Up' blocks use
+    ConvTranspose2d for conv2 / residual_conv (:57-71, :89-96)."""
+    pe = F.linear(time_pe, sd[p + "time_embedding_readout.weight"], sd[p + "time_embedding_readout.bias"])
+    second = F.conv_transpose2d if is_up else F.conv2d
+    h = act(F.conv2d(x, sd[p + "conv1.weight"], sd[p + "conv1.bias"], stride=1, padding=1))
+    h = act(second(h, sd[p + "conv2.weight"], sd[p + "conv2.bias"], stride=1, padding=1))
+    if p + "residual_conv.weight" in sd:
+        h = h + second(x, sd[p + "residual_conv.weight"], sd[p + "residual_conv.bias"], stride=1, padding=1)
+    h = h + pe[(...,) + (None,) * 2]
+    if p + "norm.weight" in sd:
+        h = F.group_norm(h, groups, sd[p + "norm.weight"], sd[p + "norm.bias"], eps=1e-5)
+    return act(h)
+
+
+def unet_v1_forward(sd: Dict[str, Tensor], cfg: dict, data: Tensor, t: Tensor) -> Tensor:
+    """UNet.forward, rho_diffusion/models/unet.py:239-269, for UNetBlock2d: time_mlp = sinusoid -> Linear (:171-174), input conv
+    3x3, the down blocks (outputs pushed), the up blocks on cat(x, popped) - the first pop returns the tensor just pushed -,
+    output conv 1x1.  cfg: the constructor kwargs (down_channels, up_channels, time_embedding_dim, activation)."""
+    act = _V1_ACT[cfg.get("activation", "ReLU")]
+    tdim = cfg.get("time_embedding_dim", 32)
+    time_pe = F.linear(sinusoidal_embedding(t, tdim), sd["time_mlp.1.weight"], sd["time_mlp.1.bias"])
+    x = F.conv2d(data, sd["input_conv.weight"], sd["input_conv.bias"], stride=1, padding=1)
+    stack: List[Tensor] = []
+    for i in range(len(cfg.get("down_channels", [64, 128, 256])) - 1):
+        x = unet_v1_block(x, time_pe, sd, f"downsample.{i}.", False, act)
+        stack.append(x)
+    for i in range(len(cfg.get("up_channels", [256, 128, 64])) - 1):
+        x = unet_v1_block(torch.cat((x, stack.pop()), dim=1), time_pe, sd, f"upsample.{i}.", True, act)
+    return F.conv2d(x, sd["output_conv.weight"], sd["output_conv.bias"])

@@ -109,6 +109,13 @@ SIGNATURES = {
                                c_int, c_int, c_void_p]),
     "rho_add_inplace": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "rho_scale_by_device_scalar": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    # ---- legacy UNet (models/unet.py)
+    "rho_act_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int, c_void_p]),
+    "rho_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    "rho_groupnorm_act": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_float,
+                                  c_int, c_void_p]),
+    "rho_groupnorm_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,
+                                      c_int64, c_int64, c_int64, c_int, c_void_p]),
     "rho_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                   c_int, c_int64, c_int64, c_int64, c_int64, c_void_p]),
 }

@@ -57,3 +57,16 @@ UPDOWN_CASES = {
                            num_heads=2, use_scale_shift_norm=True, dims=2, data_shape=[16, 24], resblock_updown=True, conv_resample=False),
                       (2, 1, 16, 24), None),
 }
+
+
+# legacy UNet ("UNet v1", models/unet.py): kwargs, input shape.  Small channel lists (multiples of 32: the HIP conv's channels-last
+# granularity) and the reference's own defaults for everything else; one GELU case (the block's default activation), one without
+# residual convolutions.
+V1_CASES = {
+    "v1_relu": (dict(block_type="UNetBlock2d", input_channels=1, down_channels=[32, 64, 96], up_channels=[96, 64, 32],
+                     time_embedding_dim=32, activation="ReLU", residual=True), (2, 1, 16, 24)),
+    "v1_gelu_rgb": (dict(block_type="UNetBlock2d", input_channels=3, down_channels=[32, 64], up_channels=[64, 32],
+                         time_embedding_dim=32, activation="GELU", residual=True), (2, 3, 16, 16)),
+    "v1_plain": (dict(block_type="UNetBlock2d", input_channels=1, down_channels=[32, 64], up_channels=[64, 32],
+                      time_embedding_dim=16, activation="SiLU", residual=False), (3, 1, 8, 8)),
+}

@@ -253,6 +253,45 @@ def test_g15_updown_and_pooled_unets(case):
     assert n > 20
 
 
+@pytest.mark.parametrize("case", ["v1_relu", "v1_gelu_rgb", "v1_plain"])
+def test_g16_legacy_unet(case):
+    """UNet v1 (rho_diffusion/models/unet.py:30-269): forward, loss and every parameter's gradient norm from the reference class."""
+    from helpers import V1_CASES
+    g = load_golden("g16_unet_v1.npz")
+    kw, xshape = V1_CASES[case]
+    x = det_normal(xshape, case + "x")
+    t = torch.tensor([(37 * i + 11) % 1000 for i in range(xshape[0])])
+    sd = {k: v.requires_grad_(True) for k, v in det_state_dict(golden_template(g, case), case).items()}
+    pred = R.unet_v1_forward(sd, dict(kw), x, t)
+    assert rel_l2(pred, torch.from_numpy(g[f"{case}/pred"])) < TOL
+    loss = torch.nn.functional.mse_loss(pred, det_normal(tuple(pred.shape), case + "tgt"))
+    assert abs(loss.item() - float(g[f"{case}/loss"])) < 1e-5
+    loss.backward()
+    n = 0
+    for k, v in sd.items():
+        assert f"{case}/grad/{k}" in g.files, k
+        ref = g[f"{case}/grad/{k}"]
+        assert abs(grad_digest_of(v.grad)[0] - ref[0]) <= 1e-4 * ref[0] + 1e-6, k
+        n += 1
+    assert n == len(sd)
+
+
+def test_g16_legacy_unet_state_dict_layout_and_registry():
+    """The drop-in class (models/unet.py) has the reference's state_dict keys / shapes in the reference's order and resolves by the
+    reference's registry names (CPU: construction only)."""
+    from helpers import V1_CASES
+    import rho_diffusion_amd  # noqa: F401
+    from rho_diffusion_amd.registry import registry
+    g = load_golden("g16_unet_v1.npz")
+    for case, (kw, _) in V1_CASES.items():
+        model = registry.get("models", "UNet")(**dict(kw))
+        got = [f"{k}|{','.join(map(str, v.shape))}" for k, v in model.state_dict().items()]
+        assert got == [str(s_) for s_ in g[f"{case}/keys"]], case
+    assert registry.get("layers", "UNetBlock2d").__name__ == "UNetBlock2d"
+    m3 = registry.get("models", "UNet")("UNetBlock3d", 1, [32, 64], [64, 32])
+    assert m3.expected_dim == 4 and isinstance(m3.input_conv, torch.nn.Conv3d)
+
+
 def test_g15_updown_modules():
     g = load_golden("g15_updown.npz")
     E = 128
