@@ -14,6 +14,8 @@
 // used directly as the next MFMA's B operand (accumulator-as-operand, rows permuted by pi), and every
 // operand that needs the contraction index contiguous is fetched from the row-major LDS tiles with the
 // transposing read ds_read_b64_tr_b16.
+#include <cstdlib>
+
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -532,6 +534,235 @@ __global__ __launch_bounds__(256) void k_attn_dkv_f32(const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ exact-f32 on the matrix cores
+// Round 3: the two kernels above on v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate = an fmaf chain per output; 64 FLOP / clk / SIMD),
+// same flash structure as the bf16 pair: the "stationary" index (query for dQ, key for dK / dV) sits on the lane, so the softmax
+// terms are lane-local, and accumulator register r of a score tile holds row (r & 3) + 8 (r >> 2) + 4 half - exactly the two rows
+// k-step r of the NEXT MFMA contracts, so P / dS feed it straight from their registers, unrounded.  (The VALU pair spent 19.6 of
+// c2's 228 ms training step on 0.4 % of its FLOPs.)
+//   k-step channel pairing of the QK^T / dO V^T contractions: half-wave h walks channels h * CH / 2 + {0 .. CH / 2 - 1}; any pairing
+//   is valid as long as both operands agree, and this one reads whole float4 pieces.
+__device__ __forceinline__ f32x16_t mma_f32(float a, float b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+template <int CH, int KT>
+__global__ __launch_bounds__(256) void k_attn_dq_f32m(const float* __restrict__ qk, const float* __restrict__ vt,
+                                                      const float* __restrict__ dout, const float* __restrict__ lse,
+                                                      const float* __restrict__ delta, float* __restrict__ dqk, int T, int C,
+                                                      float scale_log2e, float scale, int dqk_rs) {
+    constexpr int KP = CH * 4 + 16;      // K tile [key][ch], odd number of 16-byte slots per row
+    constexpr int VP = KT * 4 + 16;      // V^T tile [ch][key]
+    constexpr int NJ = CH / 8;
+    constexpr int NCT = (CH + 31) / 32;
+    constexpr int NU = KT / 32;
+    __shared__ __attribute__((aligned(16))) char k_lds[KT * KP];
+    __shared__ __attribute__((aligned(16))) char v_lds[NCT * 32 * VP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y, heads = gridDim.y;
+    const int qi = blockIdx.x * 128 + wave * 32 + col;
+    const int qc = qi < T ? qi : T - 1;
+    const size_t row2c = (size_t)2 * C;
+    float4 qf[NJ], dof[NJ];
+    {
+        const float* qp = qk + ((size_t)b * T + qc) * row2c + (size_t)h * CH + half * (CH / 2);
+        const float* dp = dout + ((size_t)b * T + qc) * C + (size_t)h * CH + half * (CH / 2);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            qf[j] = *reinterpret_cast<const float4*>(qp + 4 * j);
+            dof[j] = *reinterpret_cast<const float4*>(dp + 4 * j);
+        }
+    }
+    const float nlse_q = -lse[((size_t)b * heads + h) * T + qc];
+    const float ndel_q = -delta[((size_t)b * heads + h) * T + qc] * scale;
+    f32x16_t dq[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[ct][r] = 0.0f;
+    constexpr int KPC = CH / 4, VPC = KT / 4;
+    const bool vec_v = ((T & 3) == 0);
+    const float* const kbase = qk + (size_t)b * T * row2c + C + (size_t)h * CH;
+    const float* const vbase = vt + ((size_t)b * C + (size_t)h * CH) * T;
+
+    for (int kt0 = 0; kt0 < T; kt0 += KT) {
+        __syncthreads();
+        for (int pc = tid; pc < KT * KPC; pc += 256) {
+            const int key = pc / KPC, piece = pc % KPC;
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (kt0 + key < T) v = *reinterpret_cast<const float4*>(kbase + (size_t)(kt0 + key) * row2c + piece * 4);
+            *reinterpret_cast<float4*>(k_lds + key * KP + piece * 16) = v;
+        }
+        if (vec_v) {
+            for (int pc = tid; pc < NCT * 32 * VPC; pc += 256) {
+                const int c = pc / VPC, piece = pc % VPC;
+                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (c < CH && kt0 + piece * 4 < T) v = *reinterpret_cast<const float4*>(vbase + (size_t)c * T + kt0 + piece * 4);
+                *reinterpret_cast<float4*>(v_lds + c * VP + piece * 16) = v;
+            }
+        } else {
+            for (int e = tid; e < NCT * 32 * KT; e += 256) {
+                const int c = e / KT, key = e % KT;
+                *reinterpret_cast<float*>(v_lds + c * VP + key * 4) = (c < CH && kt0 + key < T) ? vbase[(size_t)c * T + kt0 + key] : 0.0f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            f32x16_t s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
+            const char* kp = k_lds + (32 * u + col) * KP + half * (CH / 2) * 4;
+            const char* vp = v_lds + (half * (CH / 2)) * VP + (32 * u + col) * 4;     // V^T[c][key = lane]: one float per k-step
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float4 a = *reinterpret_cast<const float4*>(kp + 16 * j);
+                s = mma_f32(a.x, qf[j].x, s); s = mma_f32(a.y, qf[j].y, s); s = mma_f32(a.z, qf[j].z, s); s = mma_f32(a.w, qf[j].w, s);
+                dp = mma_f32(*reinterpret_cast<const float*>(vp + (4 * j + 0) * VP), dof[j].x, dp);
+                dp = mma_f32(*reinterpret_cast<const float*>(vp + (4 * j + 1) * VP), dof[j].y, dp);
+                dp = mma_f32(*reinterpret_cast<const float*>(vp + (4 * j + 2) * VP), dof[j].z, dp);
+                dp = mma_f32(*reinterpret_cast<const float*>(vp + (4 * j + 3) * VP), dof[j].w, dp);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt0 + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float pv = key < T ? exp2f(fmaf(s[r], scale_log2e, nlse_q)) : 0.0f;
+                s[r] = pv * fmaf(dp[r], scale, ndel_q);            // dS^T[key][q]
+            }
+            // dQ^T[c][q] += K^T[c][key] * dS^T[key][q]: k-step r contracts the keys of accumulator register r
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const char* ka = k_lds + (32 * u + 4 * half) * KP + (32 * ct + col) * 4;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    dq[ct] = mma_f32(*reinterpret_cast<const float*>(ka + ((r & 3) + 8 * (r >> 2)) * KP), s[r], dq[ct]);
+            }
+        }
+    }
+    if (qi < T) {
+        float* op = dqk + ((size_t)b * T + qi) * dqk_rs + (size_t)h * CH;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int c = 32 * ct + 8 * rg + 4 * half;
+                if (c < CH) *reinterpret_cast<float4*>(op + c) = make_float4(dq[ct][4 * rg + 0], dq[ct][4 * rg + 1], dq[ct][4 * rg + 2], dq[ct][4 * rg + 3]);
+            }
+    }
+}
+
+template <int CH, int QT>
+__global__ __launch_bounds__(256) void k_attn_dkv_f32m(const float* __restrict__ qk, const float* __restrict__ vt,
+                                                       const float* __restrict__ dout, const float* __restrict__ lse,
+                                                       const float* __restrict__ delta, float* __restrict__ dqk, float* __restrict__ dv,
+                                                       int T, int C, float scale_log2e, float scale, int dqk_rs, int dv_rs) {
+    constexpr int QP = CH * 4 + 16;      // Q / dO tiles [query][ch]
+    constexpr int NJ = CH / 8;
+    constexpr int NCT = (CH + 31) / 32;
+    constexpr int NU = QT / 32;
+    __shared__ __attribute__((aligned(16))) char q_lds[QT * QP];
+    __shared__ __attribute__((aligned(16))) char d_lds[QT * QP];
+    __shared__ float nlse_s[QT], ndel_s[QT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y, heads = gridDim.y;
+    const int kj = blockIdx.x * 128 + wave * 32 + col;
+    const int kc = kj < T ? kj : T - 1;
+    const size_t row2c = (size_t)2 * C;
+    float4 kf[NJ], vf[NJ];
+    {
+        const float* kp = qk + ((size_t)b * T + kc) * row2c + C + (size_t)h * CH + half * (CH / 2);
+        const float* vp = vt + ((size_t)b * C + (size_t)h * CH + half * (CH / 2)) * T + kc;       // channel-major: one load per element
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            kf[j] = *reinterpret_cast<const float4*>(kp + 4 * j);
+            vf[j] = make_float4(vp[(size_t)(4 * j + 0) * T], vp[(size_t)(4 * j + 1) * T], vp[(size_t)(4 * j + 2) * T], vp[(size_t)(4 * j + 3) * T]);
+        }
+    }
+    f32x16_t dk[NCT], dvv[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[ct][r] = 0.0f; dvv[ct][r] = 0.0f; }
+    constexpr int QPC = CH / 4;
+    const float* const qbase = qk + (size_t)b * T * row2c + (size_t)h * CH;
+    const float* const dbase = dout + (size_t)b * T * C + (size_t)h * CH;
+    const float* const lbase = lse + ((size_t)b * heads + h) * T;
+    const float* const ebase = delta + ((size_t)b * heads + h) * T;
+
+    for (int qt0 = 0; qt0 < T; qt0 += QT) {
+        __syncthreads();
+        for (int pc = tid; pc < QT * QPC; pc += 256) {
+            const int q = pc / QPC, piece = pc % QPC;
+            float4 vq = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vd = vq;
+            if (qt0 + q < T) {
+                vq = *reinterpret_cast<const float4*>(qbase + (size_t)(qt0 + q) * row2c + piece * 4);
+                vd = *reinterpret_cast<const float4*>(dbase + (size_t)(qt0 + q) * C + piece * 4);
+            }
+            *reinterpret_cast<float4*>(q_lds + q * QP + piece * 16) = vq;
+            *reinterpret_cast<float4*>(d_lds + q * QP + piece * 16) = vd;
+        }
+        if (tid < QT) {
+            const bool ok = qt0 + tid < T;
+            nlse_s[tid] = ok ? -lbase[qt0 + tid] : -INFINITY;      // exp2(-inf) = 0 masks the row
+            ndel_s[tid] = ok ? -ebase[qt0 + tid] * scale : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            f32x16_t s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
+            const char* qp = q_lds + (32 * u + col) * QP + half * (CH / 2) * 4;
+            const char* dp_ = d_lds + (32 * u + col) * QP + half * (CH / 2) * 4;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float4 aq = *reinterpret_cast<const float4*>(qp + 16 * j);
+                const float4 ad = *reinterpret_cast<const float4*>(dp_ + 16 * j);
+                s = mma_f32(aq.x, kf[j].x, s); s = mma_f32(aq.y, kf[j].y, s); s = mma_f32(aq.z, kf[j].z, s); s = mma_f32(aq.w, kf[j].w, s);
+                dp = mma_f32(ad.x, vf[j].x, dp); dp = mma_f32(ad.y, vf[j].y, dp); dp = mma_f32(ad.z, vf[j].z, dp); dp = mma_f32(ad.w, vf[j].w, dp);
+            }
+            // rows of the accumulators are queries: register r <-> query 32u + (r & 3) + 8 (r >> 2) + 4 half
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int q4 = 32 * u + 8 * g + 4 * half;
+                const float4 nl = *reinterpret_cast<const float4*>(&nlse_s[q4]);
+                const float4 nd = *reinterpret_cast<const float4*>(&ndel_s[q4]);
+                const float nlv[4] = {nl.x, nl.y, nl.z, nl.w}, ndv[4] = {nd.x, nd.y, nd.z, nd.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float pv = exp2f(fmaf(s[4 * g + i], scale_log2e, nlv[i]));
+                    s[4 * g + i] = pv;                                             // P[q][key]
+                    dp[4 * g + i] = pv * fmaf(dp[4 * g + i], scale, ndv[i]);       // dS[q][key]
+                }
+            }
+            // dV^T[c][key] += dO^T[c][q] P[q][key];  dK^T[c][key] += Q^T[c][q] dS[q][key]
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const char* da = d_lds + (32 * u + 4 * half) * QP + (32 * ct + col) * 4;
+                const char* qa = q_lds + (32 * u + 4 * half) * QP + (32 * ct + col) * 4;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = ((r & 3) + 8 * (r >> 2)) * QP;
+                    dvv[ct] = mma_f32(*reinterpret_cast<const float*>(da + ro), s[r], dvv[ct]);
+                    dk[ct] = mma_f32(*reinterpret_cast<const float*>(qa + ro), dp[r], dk[ct]);
+                }
+            }
+        }
+    }
+    if (kj < T) {
+        float* ok_ = dqk + ((size_t)b * T + kj) * dqk_rs + C + (size_t)h * CH;
+        float* ov = dv + ((size_t)b * T + kj) * dv_rs + (size_t)h * CH;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int c = 32 * ct + 8 * rg + 4 * half;
+                if (c < CH) {
+                    *reinterpret_cast<float4*>(ok_ + c) = make_float4(dk[ct][4 * rg + 0], dk[ct][4 * rg + 1], dk[ct][4 * rg + 2], dk[ct][4 * rg + 3]);
+                    *reinterpret_cast<float4*>(ov + c) = make_float4(dvv[ct][4 * rg + 0], dvv[ct][4 * rg + 1], dvv[ct][4 * rg + 2], dvv[ct][4 * rg + 3]);
+                }
+            }
+    }
+}
+
 // qk [B,T,2C], vt [B,C,T], o / dout [B,T,C] channels-last; lse, delta_ws float32 [B,heads,T];
 // outputs: dqk [B,T,2C] (dq | dk), dv [B,T,C], both channels-last in `dtype`.
 extern "C" int rho_attention_bwd(const void* qk, const void* vt, const void* o, const void* dout, const float* lse,
@@ -575,6 +806,25 @@ extern "C" int rho_attention_bwd(const void* qk, const void* vt, const void* o, 
                 return RHO_E_SHAPE;
         }
 #undef RHO_ATTB
+    } else if (!(getenv("RHO_ATTN_F32_VALU") && atoi(getenv("RHO_ATTN_F32_VALU")) != 0) && ch <= 128) {
+        // exact-f32 MFMA pair (ch = 256 keeps the VALU pair: two 128-register accumulators + fragments do not fit a wave)
+        dim3 grid((unsigned)((t + 127) / 128), (unsigned)heads, (unsigned)batch), block(256);
+#define RHO_ATTB32M(chv, ktv)                                                                                                 \
+    case chv:                                                                                                                 \
+        hipLaunchKernelGGL((k_attn_dq_f32m<chv, ktv>), grid, block, 0, st, (const float*)qk, (const float*)vt,                 \
+                           (const float*)dout, lse, delta_ws, (float*)dqk, (int)t, C, sl2, scale, qrs);                        \
+        hipLaunchKernelGGL((k_attn_dkv_f32m<chv, ktv>), grid, block, 0, st, (const float*)qk, (const float*)vt,                \
+                           (const float*)dout, lse, delta_ws, (float*)dqk, (float*)dv, (int)t, C, sl2, scale, qrs, vrs);       \
+        break;
+        switch (ch) {
+            RHO_ATTB32M(16, 64)
+            RHO_ATTB32M(32, 64)
+            RHO_ATTB32M(64, 32)
+            RHO_ATTB32M(128, 32)
+            default:
+                return RHO_E_SHAPE;
+        }
+#undef RHO_ATTB32M
     } else {
         dim3 grid((unsigned)((t + 63) / 64), (unsigned)heads, (unsigned)batch), block(256);
 #define RHO_ATTB32(chv, ktv)                                                                                                  \

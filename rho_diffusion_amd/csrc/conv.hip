@@ -387,7 +387,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                 const char* src;
                 int cs, csrc;
                 halo_src(ck, src, cs, csrc);
+#ifdef RHO_PROBE_GB10   /* probe build: the whole small halo (10 pieces) in one batch - one exposed load latency per chunk instead of two */
+                constexpr int GB = (MAXP == 10) ? 10 : ((MAXP % 7 == 0) ? 7 : 5);
+#else
                 constexpr int GB = (MAXP % 7 == 0) ? 7 : 5;  // loads in flight per batch (divides MAXP)
+#endif
 #pragma unroll
                 for (int i0 = 0; i0 < MAXP; i0 += GB) {
                     uint4 v[GB];
