@@ -416,6 +416,168 @@ __global__ __launch_bounds__(256, CH <= 128 ? 2 : 1) void k_attn_dkv(const bf16_
     }
 }
 
+// ------------------------------------------------------------------------------------------------ dK and dV in one kernel (bf16)
+// Round 3: the key-stationary pair above recomputes S once per gradient (5 contractions: S, P^T dO | S, dP, dS^T Q).  Fused, S is
+// computed once (4 contractions, -20 % MFMAs of the pair).  What kept r2 from fusing was registers: two 64-register accumulators
+// plus the K and V B-operand fragments (64) left one wave per SIMD.  Here the V fragments (lane = key, 8 consecutive channels) stay
+// in LDS - the workgroup's 128 V rows are staged once as [key][ch] (transposed out of the channel-major vt) and read per k-step -
+// so a wave holds 128 (accumulators) + 32 (K fragments) + 32 (S, dP) + operands: two workgroups per CU as before.
+template <int CH, int QT>
+__global__ __launch_bounds__(256, 2) void k_attn_dkv_fused(const bf16_raw* __restrict__ qk, const bf16_raw* __restrict__ vt,
+                                                           const bf16_raw* __restrict__ dout, const float* __restrict__ lse,
+                                                           const float* __restrict__ delta, bf16_raw* __restrict__ dqk,
+                                                           bf16_raw* __restrict__ dv, int T, int C, float scale_log2e, float scale,
+                                                           int dqk_rs, int dv_rs) {
+    using QL = RowTile<CH>;
+    constexpr int KP = QL::P;
+    constexpr int VBP = CH * 2 + 16;      // V rows [key][ch]: odd number of 16-byte slots, conflict-free ds_read_b128
+    constexpr int NKK = CH / 16;
+    constexpr int NCT = (CH + 31) / 32;
+    constexpr int NU = QT / 32;
+    static_assert(CH % 32 == 0, "fused dK / dV: whole 32-channel tiles");
+    __shared__ __attribute__((aligned(16))) char q_lds[QT * KP];                 // Q  [query][ch]
+    __shared__ __attribute__((aligned(16))) char d_lds[QT * KP];                 // dO [query][ch]
+    __shared__ __attribute__((aligned(16))) char vb_lds[128 * VBP];              // V  [key][ch] of this workgroup's keys
+    __shared__ __attribute__((aligned(16))) float nlse_s[QT];
+    __shared__ __attribute__((aligned(16))) float ndel_s[QT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+    const int grp = lane >> 4, li = lane & 15, qq = li >> 2, pp = li & 3;
+    const int b = blockIdx.z, h = blockIdx.y, heads = gridDim.y;
+    const int k0 = blockIdx.x * 128;
+    const int kj = k0 + wave * 32 + col;
+    const int kc = kj < T ? kj : T - 1;
+    const size_t row2c = (size_t)2 * C;
+
+    uint4 kf[NKK];
+    {
+        const bf16_raw* kp = qk + ((size_t)b * T + kc) * row2c + C + (size_t)h * CH + 8 * half;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) kf[kk] = *reinterpret_cast<const uint4*>(kp + 16 * kk);
+    }
+    // V rows of the workgroup's 128 keys: vt is channel-major [ch][T] - a thread reads 8 consecutive keys of one channel (16 bytes)
+    // and scatters them into 8 rows; once per workgroup, outside the query sweep
+    {
+        const bf16_raw* vbase = vt + ((size_t)b * C + (size_t)h * CH) * T;
+        const bool vec = ((T & 7) == 0);
+        for (int pc = tid; pc < CH * 16; pc += 256) {
+            const int c = pc >> 4, piece = pc & 15;
+            const int key0 = k0 + piece * 8;
+            bf16_raw e[8];
+            if (vec && key0 + 8 <= T) {
+                *reinterpret_cast<uint4*>(e) = *reinterpret_cast<const uint4*>(vbase + (size_t)c * T + key0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e[j] = (key0 + j < T) ? vbase[(size_t)c * T + key0 + j] : (bf16_raw)0;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *reinterpret_cast<bf16_raw*>(vb_lds + (piece * 8 + j) * VBP + c * 2) = e[j];
+        }
+    }
+    const char* const vrow = vb_lds + (wave * 32 + col) * VBP + 16 * half;
+
+    f32x16_t adv[NCT], adk[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { adv[ct][r] = 0.0f; adk[ct][r] = 0.0f; }
+    const int prow = pi_row(col);
+
+    constexpr int QPC = CH / 8;
+    constexpr int QIT = (QT * QPC + 255) / 256;
+    constexpr bool QEXACT = (QIT * 256 == QT * QPC);
+    const bf16_raw* const qbase = qk + (size_t)b * T * row2c + (size_t)h * CH;
+    const bf16_raw* const dbase = dout + (size_t)b * T * C + (size_t)h * CH;
+    const float* const lbase = lse + ((size_t)b * heads + h) * T;
+    const float* const ebase = delta + ((size_t)b * heads + h) * T;
+
+    for (int qt0 = 0; qt0 < T; qt0 += QT) {
+        __syncthreads();                  // (first pass: also publishes vb_lds)
+        {
+            uint4 vq[QIT], vd[QIT];
+#pragma unroll
+            for (int i = 0; i < QIT; ++i) {
+                const int pc = tid + 256 * i;
+                const int q = QEXACT ? pc / QPC : min(pc / QPC, QT - 1), piece = pc % QPC;
+                const size_t qr = (size_t)min(qt0 + q, T - 1);
+                vq[i] = *reinterpret_cast<const uint4*>(qbase + qr * row2c + piece * 8);
+                vd[i] = *reinterpret_cast<const uint4*>(dbase + qr * C + piece * 8);
+            }
+            if (tid < QT) {
+                const bool ok = qt0 + tid < T;
+                nlse_s[tid] = ok ? -lbase[qt0 + tid] : -INFINITY;
+                ndel_s[tid] = ok ? -ebase[qt0 + tid] * scale : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < QIT; ++i) {
+                const int pc = tid + 256 * i;
+                const int q = pc / QPC, piece = pc % QPC;
+                if (QEXACT || pc < QT * QPC) {
+                    const bool ok = qt0 + q < T;
+                    *reinterpret_cast<uint4*>(q_lds + QL::at(q, piece * 16)) = ok ? vq[i] : make_uint4(0u, 0u, 0u, 0u);
+                    *reinterpret_cast<uint4*>(d_lds + QL::at(q, piece * 16)) = ok ? vd[i] : make_uint4(0u, 0u, 0u, 0u);
+                }
+            }
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            f32x16_t s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
+            const int qrow = 32 * u + prow;
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                const uint4 aq = *reinterpret_cast<const uint4*>(q_lds + QL::at(qrow, 16 * half + 32 * kk));
+                const uint4 ad = *reinterpret_cast<const uint4*>(d_lds + QL::at(qrow, 16 * half + 32 * kk));
+                const uint4 vf = *reinterpret_cast<const uint4*>(vrow + 32 * kk);
+                s = mma_bf16(aq, kf[kk], s);                 // S[q][key]
+                dp = mma_bf16(ad, vf, dp);                   // dP[q][key]
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int q4 = 32 * u + pi_row(8 * g + 4 * half);
+                const float4 nl = *reinterpret_cast<const float4*>(&nlse_s[q4]);
+                const float4 nd = *reinterpret_cast<const float4*>(&ndel_s[q4]);
+                const float nlv[4] = {nl.x, nl.y, nl.z, nl.w}, ndv[4] = {nd.x, nd.y, nd.z, nd.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[4 * g + j], scale_log2e, nlv[j]));
+                    s[4 * g + j] = pv;                                             // P
+                    dp[4 * g + j] = pv * fmaf(dp[4 * g + j], scale, ndv[j]);       // dS
+                }
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const uint4 bp = acc_to_frag(s, st), bs = acc_to_frag(dp, st);
+                const int rq = 32 * u + 16 * st + 8 * (grp >> 1) + qq;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    const int cb = (32 * ct + 16 * (grp & 1) + 4 * pp) * 2;
+                    const uint4 aD = tr_frag2(d_lds, QL::at(rq, cb), QL::at(rq + 4, cb));
+                    adv[ct] = mma_bf16(aD, bp, adv[ct]);     // dV^T[c][key] += dO^T[c][q] P[q][key]
+                    const uint4 aQ = tr_frag2(q_lds, QL::at(rq, cb), QL::at(rq + 4, cb));
+                    adk[ct] = mma_bf16(aQ, bs, adk[ct]);     // dK^T[c][key] += Q^T[c][q] dS[q][key]
+                }
+            }
+        }
+    }
+    if (kj < T) {
+        bf16_raw* okp = dqk + ((size_t)b * T + kj) * dqk_rs + C + (size_t)h * CH;
+        bf16_raw* ovp = dv + ((size_t)b * T + kj) * dv_rs + (size_t)h * CH;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int c = 32 * ct + 8 * rg + 4 * half;
+                *reinterpret_cast<uint2*>(okp + c) = make_uint2(pack_bf16x2(adk[ct][4 * rg + 0], adk[ct][4 * rg + 1]),
+                                                                pack_bf16x2(adk[ct][4 * rg + 2], adk[ct][4 * rg + 3]));
+                *reinterpret_cast<uint2*>(ovp + c) = make_uint2(pack_bf16x2(adv[ct][4 * rg + 0], adv[ct][4 * rg + 1]),
+                                                                pack_bf16x2(adv[ct][4 * rg + 2], adv[ct][4 * rg + 3]));
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ exact-f32 (VALU) variants
 template <int CH, int KT>
 __global__ __launch_bounds__(256) void k_attn_dq_f32(const float* __restrict__ qk, const float* __restrict__ vt,
@@ -796,15 +958,33 @@ extern "C" int rho_attention_bwd(const void* qk, const void* vt, const void* o, 
         hipLaunchKernelGGL((k_attn_dkv<chv, ktv, 1>), grid, block, 0, st, (const bf16_raw*)qk, (const bf16_raw*)vt,              \
                            (const bf16_raw*)dout, lse, delta_ws, (bf16_raw*)dqk, (int)t, C, sl2, scale, qrs, C);                 \
         break;
-        switch (ch) {
-            RHO_ATTB(16, 64)
-            RHO_ATTB(32, 64)
-            RHO_ATTB(64, 64)
-            RHO_ATTB(128, 64)
-            RHO_ATTB(256, 32)
-            default:
-                return RHO_E_SHAPE;
+        // ch = 64 (c5's heads): dQ + the fused dK / dV kernel; RHO_ATTN_DKV_SPLIT=1 keeps the r2 pair (A/B).  ch = 128 (c3) stays on the
+        // pair: fused it needs 128 accumulator + 32 K-fragment + 32 score registers + operands > 256 per wave at two waves per SIMD
+        // (hipcc: 276 bytes of scratch per lane), and one wave per SIMD is what r2 measured as slower than the extra S recompute.
+        static const bool split_env = getenv("RHO_ATTN_DKV_SPLIT") && atoi(getenv("RHO_ATTN_DKV_SPLIT")) != 0;
+#define RHO_ATTBF(chv, ktv)                                                                                                    \
+    case chv:                                                                                                                  \
+        hipLaunchKernelGGL((k_attn_dq<chv, ktv>), grid, block, 0, st, (const bf16_raw*)qk, (const bf16_raw*)vt,                  \
+                           (const bf16_raw*)dout, lse, delta_ws, (bf16_raw*)dqk, (int)t, C, sl2, scale, qrs);                   \
+        hipLaunchKernelGGL((k_attn_dkv_fused<chv, ktv>), grid, block, 0, st, (const bf16_raw*)qk, (const bf16_raw*)vt,           \
+                           (const bf16_raw*)dout, lse, delta_ws, (bf16_raw*)dqk, (bf16_raw*)dv, (int)t, C, sl2, scale, qrs, vrs); \
+        break;
+        if (!split_env && ch == 64) {
+            switch (ch) {
+                RHO_ATTBF(64, 64)
+            }
+        } else {
+            switch (ch) {
+                RHO_ATTB(16, 64)
+                RHO_ATTB(32, 64)
+                RHO_ATTB(64, 64)
+                RHO_ATTB(128, 64)
+                RHO_ATTB(256, 32)
+                default:
+                    return RHO_E_SHAPE;
+            }
         }
+#undef RHO_ATTBF
 #undef RHO_ATTB
     } else if (!(getenv("RHO_ATTN_F32_VALU") && atoi(getenv("RHO_ATTN_F32_VALU")) != 0) && ch <= 128) {
         // exact-f32 MFMA pair (ch = 256 keeps the VALU pair: two 128-register accumulators + fragments do not fit a wave)

@@ -510,16 +510,25 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     #pragma unroll
                 for (int s_ = 0; s_ < NACC; ++s_)
                     toff2[s_] = ((col >= 16 && 2 * s_ + 1 < TPW) ? tapoff[(2 * s_ + 1 < TPW) ? 2 * s_ + 1 : 0] : tapoff[2 * s_]) + (col & 15) * 4;
-                for (int kk = kk0; kk < kk1; ++kk) {
+                // operands of k-step kk + 1 are read from LDS before the MFMAs of k-step kk are issued (one wave per SIMD: nothing else
+                // covers the ~100 cycles of a dependent ds_read in front of every 5 MFMAs)
+                auto rd = [&](int kk, float& av, float (&bv)[NACC]) {
                     const int pp = 2 * kk + half;
                     const int pw = pp & (p.TW - 1), ph = (pp >> p.lgTW) & (p.TH - 1), pd = pp >> (p.lgTW + p.lgTH);
-                    const float av = *reinterpret_cast<const float*>(dyt + pp * DYP + ((col * 4) ^ dy_swz(pp)));
+                    av = *reinterpret_cast<const float*>(dyt + pp * DYP + ((col * 4) ^ dy_swz(pp)));
                     const int xr = ((pd * p.IH + ph * p.sh) * p.IW + pw * p.sw) * XP;
     #pragma unroll
-                    for (int s_ = 0; s_ < NACC; ++s_) {
-                        const float bv = *reinterpret_cast<const float*>(halo + xr + toff2[s_]);
-                        acc[s_][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[s_][0], 0, 0, 0);
-                    }
+                    for (int s_ = 0; s_ < NACC; ++s_) bv[s_] = *reinterpret_cast<const float*>(halo + xr + toff2[s_]);
+                };
+                float av0, bv0[NACC], av1, bv1[NACC];
+                rd(kk0, av0, bv0);
+                for (int kk = kk0; kk < kk1; kk += 2) {        // (kk1 - kk0 is 32 or 128: even)
+                    rd(kk + 1, av1, bv1);
+    #pragma unroll
+                    for (int s_ = 0; s_ < NACC; ++s_) acc[s_][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv0[s_], acc[s_][0], 0, 0, 0);
+                    rd(min(kk + 2, kk1 - 1), av0, bv0);
+    #pragma unroll
+                    for (int s_ = 0; s_ < NACC; ++s_) acc[s_][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv1[s_], acc[s_][0], 0, 0, 0);
                 }
             }
         }
