@@ -63,18 +63,20 @@ class SphericalHarmonicPool:
 
 @registry.register_dataset("SphericalHarmonicDataset")
 class SphericalHarmonicDataset(torch.utils.data.Dataset):
-    """The reference's synthetic dataset (data/synthetic.py:127-305) with the fields generated on the device: item = (density
+    """The reference's synthetic dataset (data/synthetic.py:127-348) with the fields generated on the device: item = (density
     float32 ``[1, G, G, G]`` on the GPU, label embedding = the 256-entry sha512 embedding of ``{"l": l, "m": m}``,
     synthetic.py:299-304).  (l, m) are drawn per item with ``random.randint`` exactly as ``random_set`` does (:240-254; the
     builtin RNG is seeded in the constructor like the reference's ``random_seed`` setter).  ``batch(B)`` draws B items with
-    ONE generator launch - what a training loop on this engine should call.  HDF5 replay (``h5_path``) is not built.
+    ONE generator launch - what a training loop on this engine should call.
+
+    HDF5 (round 3): ``h5_path`` replays pre-computed samples from disk instead of generating them (:258-261, :285-289: datasets
+    ``density``, ``l``, ``m``), ``to_hdf5`` writes such a file (:307-333) and ``from_hdf5`` opens one (:335-348) - through
+    ``h5io`` (the system libhdf5 bound with ctypes; h5py is not needed).  Rows are read one hyperslab at a time.
     ``parameter_space`` is None, as in the reference (its constructor only binds a local)."""
     parameter_space = None
 
     def __init__(self, max_l, h5_path=None, length: int = 1000, random_seed=None, use_emb_as_labels: bool = True, device="cuda",
                  **grid_kwargs):
-        if h5_path is not None:
-            raise NotImplementedError("HDF5 replay is outside the hot path (SURVEY 8f row 3); fields are generated on the device")
         if isinstance(max_l, int):
             assert max_l > 0, f"Invalid maximum value of l > 0: {max_l}"
         self.max_l = max_l
@@ -88,6 +90,22 @@ class SphericalHarmonicDataset(torch.utils.data.Dataset):
         self.random_seed = random_seed
         random.seed(random_seed)
         self.labels_emb_map = dict()
+        self.h5_path = h5_path
+        self._cursor = 0
+
+    @property
+    def h5_path(self):
+        return self._h5_path
+
+    @h5_path.setter
+    def h5_path(self, value) -> None:
+        import os
+        from pathlib import Path
+        if isinstance(value, str):
+            value = Path(value)
+        if isinstance(value, Path):
+            assert value.exists(), f"{value} passed as target HDF5 file but was not found."      # synthetic.py:181-184
+        self._h5_path = value
 
     @property
     def random_set(self) -> Tuple[int, int]:
@@ -95,20 +113,73 @@ class SphericalHarmonicDataset(torch.utils.data.Dataset):
         return (l, random.randint(-l, l))
 
     def __len__(self) -> int:
+        if self.h5_path:
+            from . import h5io
+            return h5io.shape(self.h5_path, "density")[0]
         return self.length
 
     def _label(self, l: int, m: int) -> torch.Tensor:
-        c = {"l": l, "m": m}
+        c = {"l": int(l), "m": int(m)}
         emb = calculate_sha512_embedding(c, l=256)
         self.labels_emb_map[emb] = c
         return emb
 
+    def _replay(self, index) -> Tuple[torch.Tensor, list]:
+        """Rows ``index`` (int or unit-stride slice) of the file: densities [n, 1, G, G, G] on the device + their (l, m)."""
+        from . import h5io
+        import numpy as np
+        d = h5io.read(self.h5_path, "density", index)
+        l = np.atleast_1d(h5io.read(self.h5_path, "l", index))
+        m = np.atleast_1d(h5io.read(self.h5_path, "m", index))
+        t = torch.from_numpy(np.ascontiguousarray(d, dtype=np.float32))
+        if isinstance(index, int):
+            t = t[None]
+        if t.dim() == 4:                       # [n, G, G, G] -> channel axis (files written by the reference carry it already)
+            t = t[:, None]
+        return t.to(self.device), [(int(a), int(b)) for a, b in zip(l, m)]
+
     def __getitem__(self, index: int):
+        if self.h5_path:
+            t, lm = self._replay(int(index))
+            return t[0], self._label(*lm[0])
         l, m = self.random_set
         return spherical_harmonic_field(l, m, self.grid_el, 3, self.device), self._label(l, m)
 
     def batch(self, batch_size: int):
-        lm = [self.random_set for _ in range(batch_size)]
-        data = spherical_harmonic_fields(lm, self.grid_el, 3, self.device)
+        if self.h5_path:
+            n = len(self)
+            lo = self._cursor if self._cursor + batch_size <= n else 0
+            self._cursor = lo + batch_size
+            data, lm = self._replay(slice(lo, lo + batch_size))
+        else:
+            lm = [self.random_set for _ in range(batch_size)]
+            data = spherical_harmonic_fields(lm, self.grid_el, 3, self.device)
         labels = torch.stack([self._label(l, m) for l, m in lm]).to(data.device)
         return data, labels
+
+    def to_hdf5(self, h5_path, chunk: int = 64) -> None:
+        """synthetic.py:307-333: ``len(self)`` samples -> datasets ``density`` float32 [N, G, G, G], ``l``, ``m`` and the attribute
+        ``seed``; '.h5' is appended when missing and an existing file is an error (h5py mode "x").  (The reference's own writer
+        indexes its item tuples by string and cannot run; this is the file its reader :285-289 expects.)"""
+        from pathlib import Path
+        import numpy as np
+        from . import h5io
+        path = Path(h5_path).with_suffix(".h5")
+        n = self.length if not self.h5_path else len(self)
+        dens, ls, ms = [], [], []
+        for lo in range(0, n, chunk):
+            b = min(chunk, n - lo)
+            if self.h5_path:
+                data, lm = self._replay(slice(lo, lo + b))
+            else:
+                lm = [self.random_set for _ in range(b)]
+                data = spherical_harmonic_fields(lm, self.grid_el, 3, self.device)
+            dens.append(data[:, 0].cpu().numpy())
+            ls += [a for a, _ in lm]
+            ms += [c for _, c in lm]
+        h5io.write(path, {"density": np.concatenate(dens, 0), "l": np.asarray(ls, dtype=np.int64), "m": np.asarray(ms, dtype=np.int64)},
+                   attrs={"seed": int(self.random_seed)}, mode="x")
+
+    @classmethod
+    def from_hdf5(cls, h5_path, **kwargs) -> "SphericalHarmonicDataset":
+        return cls(max_l=None, h5_path=h5_path, **kwargs)

@@ -32,6 +32,14 @@ def save_model_checkpoint(model, filename):
     torch.save(model.state_dict(), filename)
 
 
+def save_samples_h5(filename, samples, name: str = "data") -> None:
+    """scripts/inference.py:168-169: ``with h5py.File(fn, "w") as h5f: h5f["data"] = pred_images.cpu().numpy()`` - the file the
+    reference's plotting reads back.  Written through ``h5io`` (system libhdf5 over ctypes, no h5py)."""
+    from . import h5io
+    arr = samples.detach().cpu().numpy() if torch.is_tensor(samples) else np.asarray(samples)
+    h5io.write(filename, {name: arr}, mode="w")
+
+
 def calculate_sha512_embedding(d: dict, l: int = 128):
     """utils.py:170-177: ASCII codes of the sha512 hex digest / 128, repeated to length l."""
     h = hashlib.sha512(json.dumps(d, sort_keys=True).encode()).hexdigest()

@@ -204,3 +204,36 @@ def test_use_checkpoint_recomputes_in_backward_same_gradients_less_memory(case, 
         d = float((res[True][1][n].double() - gr.double()).norm())
         assert d <= 1e-5 * float(gr.double().norm()) + 1e-9, (n, d)
     assert res[True][2] < 0.9 * res[False][2], (res[True][2], res[False][2])      # (tiny nets: 0.81; c3 at B = 32: see DESIGN.md)
+
+
+# ----------------------------------------------------------------------------- HDF5 replay of the synthetic dataset
+def test_spherical_harmonic_dataset_to_hdf5_and_replay(tmp_path):
+    """synthetic.py:307-348: fields generated on the device are serialised (density / l / m / seed) and replayed from disk: the
+    replayed items equal the generated ones bit for bit, carry the same label embeddings, and feed a training step."""
+    from rho_diffusion_amd import h5io
+    from rho_diffusion_amd.data import SphericalHarmonicDataset, spherical_harmonic_fields
+    if not h5io.available():
+        pytest.skip("libhdf5 not found on this machine")
+    ds = SphericalHarmonicDataset(3, length=6, random_seed=11, grid_el=16, device=DEV)
+    ds.to_hdf5(tmp_path / "sh")                                      # '.h5' is appended (synthetic.py:320-321)
+    path = tmp_path / "sh.h5"
+    assert h5io.shape(path, "density") == (6, 16, 16, 16) and h5io.read_attr(path, "seed") == 11
+    l, m = h5io.read(path, "l"), h5io.read(path, "m")
+    assert all(0 <= a <= 3 and abs(b) <= a for a, b in zip(l, m))
+    ref = spherical_harmonic_fields(list(zip(l.tolist(), m.tolist())), 16, 3, DEV)
+    rep = SphericalHarmonicDataset.from_hdf5(path, device=DEV)
+    assert len(rep) == 6
+    for i in (0, 5):
+        x, emb = rep[i]
+        assert x.is_cuda and torch.equal(x, ref[i]) and emb.shape == (256,)
+    data, labels = rep.batch(4)
+    assert torch.equal(data, ref[:4]) and labels.shape == (4, 256)
+    # the replayed batch trains: q_sample + UNet forward / backward on the HIP path
+    from rho_diffusion_amd.diffusion import DDPM, LinearSchedule
+    from rho_diffusion_amd.models import UNet
+    kw = dict(data_shape=[16, 16, 16], in_channels=1, out_channels=1, model_channels=32, num_res_blocks=1, channel_mult=(1, 2),
+              attention_resolutions=[], num_heads=2, use_scale_shift_norm=True, dims=3, compute_dtype="bf16")
+    ddpm = DDPM(UNet, kw, LinearSchedule(50, 1e-3, 0.02), nn.MSELoss, timesteps=50).to(DEV).train()
+    loss = ddpm.training_step(data)
+    loss.backward()
+    assert torch.isfinite(loss)
