@@ -94,7 +94,8 @@ def test_bench_gpus_flag_takes_the_launcher_branch(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                         "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
-    assert "[launch] rank" in r.stderr and "[rank 1]" in r.stderr, r.stderr[-2000:]
+    # (whichever rank fails first is reported; the other is stopped by the launcher, possibly before it printed anything)
+    assert "[launch] rank" in r.stderr and "stopping the other ranks" in r.stderr, r.stderr[-2000:]
     assert '"n_gpus"' not in r.stdout
 
 
