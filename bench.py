@@ -464,7 +464,8 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": workload_name(args, world), "global_batch": B * world,
                    "parallelism": f"independent samples x{world} (sampling: no data-path collective; training: DP gradient "
-                                  f"all-reduce over RCCL, overlapped with backward)"},
+                                  f"all-reduce over {'RCCL' if not dist.is_initialized() or dist.get_backend() == 'nccl' else dist.get_backend()}, "
+                                  f"overlapped with backward)"},
     }
     if "sample" in results:
         out["config"]["hip_graph"] = bool(results["sample"].get("graphed"))
@@ -485,7 +486,9 @@ def main():
                            "steps": r["steps"], "ms_per_step": 1e3 * r["dt"] / r["steps"], "ms_per_step_hipevent_median": r["median_ms"],
                            "loss": r["loss"],
                            "peak_mem_gb": r.get("peak_mem_gb"), "plan_gb": r.get("plan_gb"),
-                           "step": "q_sample + UNetv2 fwd + MSE + bwd + " + ("RCCL grad all-reduce + " if world > 1 else "") + "fused AdamW"}
+                           "step": "q_sample + UNetv2 fwd + MSE + bwd + "
+                                   + ((("RCCL" if dist.get_backend() == "nccl" else dist.get_backend()) + " grad all-reduce + ") if world > 1 else "")
+                                   + "fused AdamW"}
 
     if roofline is not None:
         out["roofline"] = roofline
