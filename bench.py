@@ -64,6 +64,7 @@ PRESETS = {
     "c1": dict(dims=2, grid=64, mc=64, batch=16, dtype="fp32", labels=False),
     "c2": dict(dims=2, grid=128, mc=64, batch=64, dtype="fp32", labels=False),
     "c3": dict(dims=3, grid=64, mc=64, batch=32, dtype="bf16", labels=False),
+    "c4": dict(dims=3, grid=64, mc=64, batch=32, dtype="bf16", labels=False),      # = c3 per GPU; run with --gpus 8 (global batch 256)
     "c5": dict(dims=3, grid=128, mc=32, batch=2, dtype="bf16", labels=True),
 }
 DEEP_GALAXY_SPACE = {"s": [0.25, 0.5, 0.75, 1, 1.25, 1.5], "m": [0.25, 0.5, 0.75, 1, 1.25, 1.5],
@@ -76,7 +77,7 @@ def workload_name(args, world):
     for name, pz in PRESETS.items():
         if all(getattr(args, k) == v for k, v in pz.items()):
             which = {"c1": "configs[0]", "c2": "configs[1]", "c3": "configs[2]" if world == 1 else f"configs[3] on {world} GPUs",
-                     "c5": "configs[4] geometry (batch 2/GPU)"}[name]
+                     "c4": "configs[2]" if world == 1 else f"configs[3] on {world} GPUs", "c5": "configs[4] geometry (batch 2/GPU)"}[name]
     tag = f"BASELINE {which}" if which else "custom configuration, not a BASELINE config"
     cond = ", class-conditional (MultiEmbeddings y[B,4])" if args.labels else ""
     return (f"DDPM reverse step, UNetv2 {args.dims}D {args.grid}^{args.dims} mc={args.mc}{cond} ({tag}), batch {args.batch}/GPU, "

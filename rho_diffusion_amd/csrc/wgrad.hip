@@ -48,6 +48,7 @@ struct WgradK {
     // the output position; dY row of output row oh: oh * oy_mul + oy_add in a tensor of Ho_out x Wo_out rows per depth slice
     int pad_h, pad_w, oy_mul, oy_add, ox_mul, ox_add, Ho_out, Wo_out;
     int xcd_map;        // 1: workgroups of one position slab (all cout tiles x cin chunks) on consecutive launch slots of one XCD
+    int pairc;          // f32 1x1x1: a workgroup owns TWO 16-channel input chunks (the upper 16 B columns of the MFMA carry the second)
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -100,6 +101,9 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     // Round 3: the other 16 columns carry the SAME channels at the wave's NEXT tap (a per-lane tap offset), so one MFMA reduces
     // two taps (r02 fed them zeros: c2's weight gradient ran at 0.18 of the f32 matrix peak, 184 of 314 ms per training step).
     constexpr int NACC = IS_BF16 ? TPW : (TPW + 1) / 2;
+    // ... and a 1x1x1 launch has no second tap: there the upper columns carry the NEXT 16-channel chunk (p.pairc; the workgroup stages
+    // both chunks, the second at halo rows 256 .. 511: slots 4 .. 7 of every thread)
+    constexpr bool PAIRC = !IS_BF16 && NT == 1;
     constexpr int NKS = TAPSPLIT ? 16 : 4;           // 16-position k-steps of this wave per tile
     constexpr bool KEEP_REL = (MAXP <= 10);          // big-halo (strided) variant recomputes instead of holding registers
     // PIPE (bf16, regular halo): the LDS tiles are DOUBLE-BUFFERED (2 x (40 KB halo + 32 KB dY) = 144 of the 160 KB) and the staging
@@ -132,11 +136,20 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
         by = pi / (int)gridDim.z;
     }
     const int co0 = by * COT;
-    const int c = bz * CK;        // input-channel chunk of this workgroup
+    const bool pairc = PAIRC && p.pairc != 0;
+    const int c = bz * CK * (pairc ? 2 : 1);        // (first) input-channel chunk of this workgroup
     const char* src;
     int cs, csrc;
     if (c < p.c1) { src = p.x1; cs = p.c1; csrc = c; } else { src = p.x2; cs = p.c2; csrc = c - p.c1; }
     src += (size_t)csrc * sizeof(T) + piece * 16;
+    const bool has2 = pairc && (c + CK < p.cin);    // second chunk of the pair (may lie in the other concat source)
+    const char* src2 = src;
+    int cs2 = cs;
+    if (has2) {
+        const int cb = c + CK;
+        if (cb < p.c1) { src2 = p.x1 + (size_t)cb * sizeof(T) + piece * 16; cs2 = p.c1; }
+        else { src2 = p.x2 + (size_t)(cb - p.c1) * sizeof(T) + piece * 16; cs2 = p.c2; }
+    }
 
     // halo slot -> (id, ih, iw) and its offset (in positions) from the tile's first halo position: fixed for every tile
     int sdec[MAXP], srel[KEEP_REL ? MAXP : 1];
@@ -144,9 +157,12 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
         const int ihw = p.IH * p.IW;
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
-            const int hp = (tid >> 2) + 64 * i;
+            const int hp0 = (tid >> 2) + 64 * i;
+            // (pair mode: slots 4 .. 7 hold the second chunk's copy of rows 0 .. 255)
+            const bool sec = PAIRC && pairc && i >= 4 && i < 8;
+            const int hp = sec ? hp0 - 256 : hp0;
             int v = -1, rel = 0;
-            if (hp < p.NP) {
+            if (hp < p.NP && (!sec || has2) && !(PAIRC && pairc && !sec && i >= 4)) {
                 const int id = hp / ihw;
                 const int r = hp - id * ihw;
                 const int ih = r / p.IW;
@@ -259,7 +275,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
             const int rel = KEEP_REL ? srel[KEEP_REL ? i : 0] : (id * p.H + ih) * p.W + iw;
             const int pos = ok ? base + rel : 0;
             xpos[i] = ok ? pos : -1;
-            xv[i] = *reinterpret_cast<const uint4*>(src + (size_t)pos * cs * sizeof(T));
+            if (PAIRC && i >= 4 && i < 8)      // (slots of the second chunk; without pair mode they are invalid and read position 0 of src2 = src)
+                xv[i] = *reinterpret_cast<const uint4*>(src2 + (size_t)pos * cs2 * sizeof(T));
+            else
+                xv[i] = *reinterpret_cast<const uint4*>(src + (size_t)pos * cs * sizeof(T));
         }
     };
     auto issue_dy = [&]() {
@@ -288,7 +307,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
             if constexpr (PRE) {
                 if (xpos[i] >= 0) {
                     const int smp = (KD == 3) ? n_cur : (int)((unsigned)xpos[i] / (unsigned)p.S_in);
-                    const size_t co = (size_t)smp * p.cin + c + piece * PE;
+                    const size_t co = (size_t)smp * p.cin + c + ((PAIRC && pairc && i >= 4) ? CK : 0) + piece * PE;
                     u = apply_pre<T>(u, p.pre_a + co, p.pre_b + co, p.pre_silu);
                 }
             }
@@ -509,7 +528,8 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
                 int toff2[NACC];
     #pragma unroll
                 for (int s_ = 0; s_ < NACC; ++s_)
-                    toff2[s_] = ((col >= 16 && 2 * s_ + 1 < TPW) ? tapoff[(2 * s_ + 1 < TPW) ? 2 * s_ + 1 : 0] : tapoff[2 * s_]) + (col & 15) * 4;
+                    toff2[s_] = ((col >= 16 && 2 * s_ + 1 < TPW) ? tapoff[(2 * s_ + 1 < TPW) ? 2 * s_ + 1 : 0] : tapoff[2 * s_]) + (col & 15) * 4 +
+                                ((PAIRC && has2 && col >= 16) ? 256 * XP : 0);
                 // operands of k-step kk + 1 are read from LDS before the MFMAs of k-step kk are issued (one wave per SIMD: nothing else
                 // covers the ~100 cycles of a dependent ds_read in front of every 5 MFMAs)
                 auto rd = [&](int kk, float& av, float (&bv)[NACC]) {
@@ -575,12 +595,14 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
         const bool upper = (lane & 31) >= 16;
 #pragma unroll
         for (int s_ = 0; s_ < NACC; ++s_) {
-            const int tap = upper ? ((2 * s_ + 1 < TPW) ? tap_of[(2 * s_ + 1 < TPW) ? 2 * s_ + 1 : 0] : NT) : tap_of[2 * s_];
+            int tap = upper ? ((2 * s_ + 1 < TPW) ? tap_of[(2 * s_ + 1 < TPW) ? 2 * s_ + 1 : 0] : NT) : tap_of[2 * s_];
+            int cif = ci;
+            if (PAIRC && has2 && upper) { tap = tap_of[0]; cif = ci + CK; }      // 1x1x1 pair mode: the same tap, the next chunk
             if (tap < NT) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (co < p.coutp) atomicAdd(p.dw + ((size_t)tap * p.coutp + co) * p.cin + ci, acc[s_][0][r]);
+                    if (co < p.coutp) atomicAdd(p.dw + ((size_t)tap * p.coutp + co) * p.cin + cif, acc[s_][0][r]);
                 }
             }
         }
@@ -895,7 +917,11 @@ static int wgrad_impl(const rho_conv_desc* dp, const void* dy, int64_t dy_width,
     // One workgroup per CU (144 KB of LDS) and equal slabs: the launch runs in rounds of n_cu workgroups.  Pick the slab count so
     // that splits x pairs fills 3..6 whole rounds (was ceil(1024 / pairs): 6 pairs -> 1026 workgroups = a fifth round of two,
     // 20 % of the launch, on every layer whose channel count is 3 * 2^k - the concatenated inputs of the output blocks).
-    const int pairs = cdiv(d.coutp, COT) * (cin / CK);
+    // f32 1x1x1: a workgroup takes two input-channel chunks (k_wgrad's PAIRC), so the chunk axis of the grid halves
+    const bool pairc = d.dtype == RHO_F32 && d.kd * d.kh * d.kw == 1 && t.NP == 256 && cdiv(t.NP, 64) <= 10;
+    k.pairc = pairc ? 1 : 0;
+    const int nchunk = pairc ? cdiv(cin / CK, 2) : cin / CK;
+    const int pairs = cdiv(d.coutp, COT) * nchunk;
     static const int n_cu = []() { hipDeviceProp_t pr; int dev = 0; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
     int splits = cdiv(4 * n_cu, pairs);
     double best = -1.0;
@@ -911,8 +937,8 @@ static int wgrad_impl(const rho_conv_desc* dp, const void* dy, int64_t dy_width,
     if (splits > k.tiles_total) splits = k.tiles_total;
     k.tiles_per_block = cdiv(k.tiles_total, splits);
     splits = cdiv(k.tiles_total, k.tiles_per_block);
-    if (cdiv(d.coutp, COT) > 65535 || cin / CK > 65535) return RHO_E_SHAPE;
-    dim3 grid((unsigned)splits, (unsigned)cdiv(d.coutp, COT), (unsigned)(cin / CK));
+    if (cdiv(d.coutp, COT) > 65535 || nchunk > 65535) return RHO_E_SHAPE;
+    dim3 grid((unsigned)splits, (unsigned)cdiv(d.coutp, COT), (unsigned)nchunk);
     static const bool xcd_env = !(getenv("RHO_WGRAD_XCD") && atoi(getenv("RHO_WGRAD_XCD")) == 0);
     k.xcd_map = (xcd_env && splits % 8 == 0 && (long long)splits * pairs < (1LL << 31)) ? 1 : 0;
     const int maxp = cdiv(t.NP, 64);

@@ -120,6 +120,40 @@ def test_conv_dgrad_and_wgrad(ops, dtype, case):
     assert rel_l2(dbias[:cout], ref_db) < 1e-5 and float(dbias[cout:].abs().max() if dbias.numel() > cout else 0.0) == 0.0, f"dbias {name}"
 
 
+@pytest.mark.parametrize("c1,c2,pre", [(48, 32, False), (16, 0, False), (64, 16, False), (48, 32, True), (96, 0, True)],
+                         ids=["straddle_odd", "single_chunk", "even", "straddle_odd_pre", "pre"])
+def test_conv_wgrad_f32_1x1_chunk_pairs(ops, c1, c2, pre):
+    """Exact-f32 1x1x1 weight gradient: a workgroup owns TWO 16-channel input chunks (the upper 16 columns of the MFMA's B operand
+    carry the second; wgrad.hip PAIRC).  Cases: a pair that straddles the two concat sources with an odd chunk count (the last
+    workgroup has no second chunk), a single chunk, an even count; with and without the prologue in the loader; partial last tile."""
+    dims, N, cout, spatial = 2, 3, 64, (9, 13)                       # 351 positions: one full 256-position tile + a partial one
+    cin = c1 + c2
+    x = det_normal((N, cin, *spatial), f"cp{c1}{c2}x")
+    w = (det_normal((cout, cin, 1, 1), f"cp{c1}{c2}w") / math.sqrt(cin)).requires_grad_(True)
+    a = 1 + 0.3 * det_normal((N, cin), "cpa")
+    b = 0.2 * det_normal((N, cin), "cpb")
+    sh = (N, cin, 1, 1)
+    act = F.silu(a.reshape(sh) * x + b.reshape(sh)) if pre else x
+    y = F.conv2d(act, w)
+    dy = det_normal(tuple(y.shape), "cpdy")
+    y.backward(dy)
+    f32 = torch.float32
+    wf = ops.prep_conv_weight(w.detach().to(DEV), f32)
+    x1cl = to_cl(x[:, :c1], f32)
+    x2cl = to_cl(x[:, c1:], f32) if c2 else None
+    dycl = to_cl(dy, f32)
+    zb, a_d, b_d = torch.zeros(wf.shape[1], device=DEV), a.to(DEV), b.to(DEV)
+    d = ops.make_conv_desc(x1cl, x2cl, wf, zb, kernel=(1, 1, 1), cout=cout, split=cout, y=dycl, y2=None,
+                           pre_a=a_d if pre else None, pre_b=b_d if pre else None, pre_silu=pre)
+    dwbuf = torch.zeros(tuple(wf.shape), dtype=torch.float32, device=DEV)
+    dbias = torch.zeros(wf.shape[1], dtype=torch.float32, device=DEV)
+    ops.conv_wgrad(d, dycl, dwbuf, dbias)
+    grad = torch.zeros(tuple(w.shape), device=DEV)
+    ops.wgrad_finalize(dwbuf, grad)
+    assert rel_l2(grad, w.grad) < 5e-5
+    assert rel_l2(dbias[:cout], dy.sum((0, 2, 3))) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_wgrad_with_prologue(ops, dtype):
     """wgrad recomputes SiLU(a*x+b) in its loader."""
