@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     // one barrier per tile.  The single-buffered form ran load-wait / LDS-write / barrier / address set-up as a serial phase per
     // tile with nothing to overlap it (one wave per SIMD: 224 accumulator registers) - PMC r01h: the matrix pipe busy 57 % of the
     // wave's cycles, 19 % in staging VALU, 18 % parked in waits.
-    constexpr bool PIPE = IS_BF16 && KEEP_REL;
+    constexpr bool PIPE = KEEP_REL;          // (round 3: the exact-f32 variants too - their serial load-wait / LDS-write phase cost 47 % of the tile)
     constexpr int XBUF = MAXP * 64 * XP;
     constexpr int DBUF = 256 * DYP;
     constexpr int BUF = XBUF + DBUF;
@@ -338,6 +338,56 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     using IH = std::integral_constant<int, MAXP / 2>;
     using IM = std::integral_constant<int, MAXP>;
 
+    // exact-f32 reduction of one staged tile (halo_ / dyt_: the LDS images of that tile)
+    auto f32_tile = [&](const char* halo_, const char* dyt_, auto&& between) {
+                // exact f32: k = position pair (2*kk + half); columns 0-15 = the 16 channels at tap 2s, columns 16-31 = the same
+        // channels at tap 2s + 1 of this wave (an odd tap count leaves the last slot's upper half on a repeat that is not flushed)
+        const int kk0 = TAPSPLIT ? 0 : wave * 32;
+        const int kk1 = TAPSPLIT ? 128 : wave * 32 + 32;
+        const int col = lane & 31;
+        int toff2[NACC];
+    #pragma unroll
+        for (int s_ = 0; s_ < NACC; ++s_)
+            toff2[s_] = ((col >= 16 && 2 * s_ + 1 < TPW) ? tapoff[(2 * s_ + 1 < TPW) ? 2 * s_ + 1 : 0] : tapoff[2 * s_]) + (col & 15) * 4 +
+                        ((PAIRC && has2 && col >= 16) ? 256 * XP : 0);
+        // operands of k-step kk + 1 are read from LDS before the MFMAs of k-step kk are issued (one wave per SIMD: nothing else
+        // covers the ~100 cycles of a dependent ds_read in front of every 5 MFMAs)
+        auto rd = [&](int kk, float& av, float (&bv)[NACC]) {
+            const int pp = 2 * kk + half;
+            const int pw = pp & (p.TW - 1), ph = (pp >> p.lgTW) & (p.TH - 1), pd = pp >> (p.lgTW + p.lgTH);
+            av = *reinterpret_cast<const float*>(dyt_ + pp * DYP + ((col * 4) ^ dy_swz(pp)));
+            const int xr = ((pd * p.IH + ph * p.sh) * p.IW + pw * p.sw) * XP;
+    #pragma unroll
+            for (int s_ = 0; s_ < NACC; ++s_) bv[s_] = *reinterpret_cast<const float*>(halo_ + xr + toff2[s_]);
+        };
+        // MFMA intrinsics carry no chain, so the scheduler sinks the reads of the NEXT k-step below the current MFMAs and then waits for
+        // them right in front of their use (measured: the reduction alone ran at 62 % of the f32 MFMA rate).  As in k_conv: an empty
+        // volatile asm that passes the operands the next MFMAs use (data dependence) with a memory clobber pins the source order -
+        // the reads of k-step kk + 1 are issued, THEN the MFMAs of k-step kk.
+        auto pin = [&](float& av, float (&bv)[NACC]) {
+            asm volatile("" : "+v"(av) : : "memory");
+    #pragma unroll
+            for (int s_ = 0; s_ < NACC; ++s_) asm volatile("" : "+v"(bv[s_]) : : "memory");
+        };
+        float av0, bv0[NACC], av1, bv1[NACC];
+        rd(kk0, av0, bv0);
+        constexpr int NIT2 = TAPSPLIT ? 64 : 16;        // (kk1 - kk0 is 128 or 32)
+        // (compile-time unrolled: the row offsets of every k-step fold into per-lane constants, and `between(IT)` - the DMA path's
+        //  share of the next tile's address set-up - lands between the MFMA groups)
+        static_for<NIT2>([&](auto IT) {
+            constexpr int it = decltype(IT)::value;
+            const int kk = kk0 + 2 * it;
+            rd(kk + 1, av1, bv1);
+            pin(av0, bv0);
+    #pragma unroll
+            for (int s_ = 0; s_ < NACC; ++s_) acc[s_][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv0[s_], acc[s_][0], 0, 0, 0);
+            between(IT);
+            rd(min(kk + 2, kk1 - 1), av0, bv0);
+            pin(av1, bv1);
+    #pragma unroll
+            for (int s_ = 0; s_ < NACC; ++s_) acc[s_][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv1[s_], acc[s_][0], 0, 0, 0);
+        });
+    };
     if constexpr (DMA) {
         // ------------------------------------------------------------------ double-buffered LDS tiles filled by LDS-DMA
         // Phase of tile t: (1) issue the 18 global_load_lds_dwordx4 of tile t+1 into the other buffer (addresses were computed
@@ -380,7 +430,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
                 const int id = sdec[i] >> 20, ih = (sdec[i] >> 10) & 1023, iw = sdec[i] & 1023;
                 const bool ok = (sdec[i] >= 0) & ((unsigned)(gd_base + id) < (unsigned)p.D) & ((unsigned)(gh_base + ih) < (unsigned)p.H) &
                                 ((unsigned)(gw_base + iw) < (unsigned)p.W);
-                ax[i] = ok ? src + (size_t)(base + srel[i]) * cs * sizeof(T) : zpage;
+                if (PAIRC && i >= 4 && i < 8)          // (f32 1x1x1 pair mode: slots 4 .. 7 = the second chunk)
+                    ax[i] = ok ? src2 + (size_t)(base + srel[i]) * cs2 * sizeof(T) : zpage;
+                else
+                    ax[i] = ok ? src + (size_t)(base + srel[i]) * cs * sizeof(T) : zpage;
             } else {
                 constexpr int i = sl - MAXP;
                 const int pd = ddec[i] >> 20, ph = (ddec[i] >> 10) & 1023, pw = ddec[i] & 1023;
@@ -423,48 +476,71 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
         }
         for (int tl = tile0; tl < tile1; ++tl) {
             const int rdb = ((tl - tile0) & 1) * BUF, wrb = BUF - rdb;
+#ifdef RHO_PROBE_F32_NODMA
+            if constexpr (IS_BF16)
+#endif
             dma(wrb);                                       // tile tl + 1 (past the end: a harmless re-read of the last tile)
             decode2(min(tl + 2, tile1 - 1));                // its slot addresses are dealt into the k-steps below
+            if constexpr (IS_BF16) {
             int tob[TPW], ab[MT];
 #pragma unroll
-            for (int ti = 0; ti < TPW; ++ti) tob[ti] = tapoff[ti] + rdb;
+                for (int ti = 0; ti < TPW; ++ti) tob[ti] = tapoff[ti] + rdb;
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi) ab[mi] = arow[mi] + rdb + XBUF;
-            // Fragments of k-step j + 1 are read from LDS BEFORE the 14 MFMAs of k-step j are issued (two register sets): with one
-            // wave per SIMD nothing else covers the ~100+ cycles of a transposing read.
-            uint4 fa[2][MT], fb[2][TPW];
-            auto rd_frags = [&](auto J) {
-                constexpr int j = decltype(J)::value;
-                constexpr int s_ = j & 1;
-                const int sj = ((j & 1) ? kc[0] : 0) + ((j & 2) ? kc[1] : 0) + ((j & 4) ? kc[2] : 0) + ((j & 8) ? kc[3] : 0);   // scalar
+                for (int mi = 0; mi < MT; ++mi) ab[mi] = arow[mi] + rdb + XBUF;
+                // Fragments of k-step j + 1 are read from LDS BEFORE the 14 MFMAs of k-step j are issued (two register sets): with one
+                // wave per SIMD nothing else covers the ~100+ cycles of a transposing read.
+                uint4 fa[2][MT], fb[2][TPW];
+                auto rd_frags = [&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    constexpr int s_ = j & 1;
+                    const int sj = ((j & 1) ? kc[0] : 0) + ((j & 2) ? kc[1] : 0) + ((j & 4) ? kc[2] : 0) + ((j & 8) ? kc[3] : 0);   // scalar
 #pragma unroll
-                for (int mi = 0; mi < MT; ++mi) fa[s_][mi] = tr_frag(smem, ab[mi] + j * 16 * DYP, ab[mi] + (j * 16 + 4) * DYP);
+                    for (int mi = 0; mi < MT; ++mi) fa[s_][mi] = tr_frag(smem, ab[mi] + j * 16 * DYP, ab[mi] + (j * 16 + 4) * DYP);
 #pragma unroll
-                for (int ti = 0; ti < TPW; ++ti) fb[s_][ti] = tr_frag(smem, xb[0] + (tob[ti] + sj), xb[1] + (tob[ti] + sj));
-            };
-            rd_frags(std::integral_constant<int, 0>{});
-            static_for<NKS>([&](auto J) {
-                constexpr int j = decltype(J)::value;
-                if constexpr (j + 1 < NKS) rd_frags(std::integral_constant<int, j + 1>{});
+                    for (int ti = 0; ti < TPW; ++ti) fb[s_][ti] = tr_frag(smem, xb[0] + (tob[ti] + sj), xb[1] + (tob[ti] + sj));
+                };
+                rd_frags(std::integral_constant<int, 0>{});
+                static_for<NKS>([&](auto J) {
+                    constexpr int j = decltype(J)::value;
+                    if constexpr (j + 1 < NKS) rd_frags(std::integral_constant<int, j + 1>{});
 #pragma unroll
-                for (int ti = 0; ti < TPW; ++ti)
+                    for (int ti = 0; ti < TPW; ++ti)
 #pragma unroll
-                    for (int mi = 0; mi < MT; ++mi) mma_step<T>(fa[j & 1][mi], fb[j & 1][ti], acc[ti][mi]);
-                // this k-step's share of the address set-up of tile tl + 2 (pure VALU, hidden under the MFMAs)
-                static_for<NSLOT>([&](auto SL) {
-                    if constexpr ((decltype(SL)::value * NKS) / NSLOT == j) addr_slot(SL);
+                        for (int mi = 0; mi < MT; ++mi) mma_step<T>(fa[j & 1][mi], fb[j & 1][ti], acc[ti][mi]);
+                    // this k-step's share of the address set-up of tile tl + 2 (pure VALU, hidden under the MFMAs)
+                    static_for<NSLOT>([&](auto SL) {
+                        if constexpr ((decltype(SL)::value * NKS) / NSLOT == j) addr_slot(SL);
+                    });
                 });
-            });
+            } else {
+                // exact f32: the same double-buffered DMA staging, the f32 reduction (two taps / chunks per MFMA) on buffer rdb;
+                // the address set-up of tile tl + 2 follows it (pure VALU)
+#ifndef RHO_PROBE_F32_NOMMA      /* timing probes (wrong results): -DRHO_PROBE_F32_NOMMA skips the reduction, _NODMA the staging */
+                constexpr int NIT2_ = TAPSPLIT ? 64 : 16;
+                f32_tile(smem + rdb, smem + rdb + XBUF, [&](auto IT) {
+                    static_for<NSLOT>([&](auto SL) {
+                        if constexpr ((decltype(SL)::value * NIT2_) / NSLOT == decltype(IT)::value) addr_slot(SL);
+                    });
+                });
+#else
+                static_for<NSLOT>([&](auto SL) { addr_slot(SL); });
+#endif
+            }
             if (do_bias) {
                 // bias gradient = channel sums of dY: this thread's 8 pieces of the tile just reduced (LDS slot tid * 16 of
                 // each 4 KB dY slot holds channel piece dsw); only the workgroups of input-channel chunk 0 (uniform branch)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const uint4 u = *reinterpret_cast<const uint4*>(smem + rdb + XBUF + tid * 16 + i * 4096);
-                    bsum[0] += __uint_as_float(u.x << 16); bsum[1] += __uint_as_float(u.x & 0xFFFF0000u);
-                    bsum[2] += __uint_as_float(u.y << 16); bsum[3] += __uint_as_float(u.y & 0xFFFF0000u);
-                    bsum[4] += __uint_as_float(u.z << 16); bsum[5] += __uint_as_float(u.z & 0xFFFF0000u);
-                    bsum[6] += __uint_as_float(u.w << 16); bsum[7] += __uint_as_float(u.w & 0xFFFF0000u);
+                    if constexpr (IS_BF16) {
+                        bsum[0] += __uint_as_float(u.x << 16); bsum[1] += __uint_as_float(u.x & 0xFFFF0000u);
+                        bsum[2] += __uint_as_float(u.y << 16); bsum[3] += __uint_as_float(u.y & 0xFFFF0000u);
+                        bsum[4] += __uint_as_float(u.z << 16); bsum[5] += __uint_as_float(u.z & 0xFFFF0000u);
+                        bsum[6] += __uint_as_float(u.w << 16); bsum[7] += __uint_as_float(u.w & 0xFFFF0000u);
+                    } else {
+                        bsum[0] += __uint_as_float(u.x); bsum[1] += __uint_as_float(u.y);
+                        bsum[2] += __uint_as_float(u.z); bsum[3] += __uint_as_float(u.w);
+                    }
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile tl + 1 have landed ...
@@ -520,36 +596,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
                     for (int j = 0; j < NKS; ++j) kstep(j, xrow_of(j, 0), xrow_of(j, 1));   // rolled: keeps the decode out of registers
                 }
             } else {
-                // exact f32: k = position pair (2*kk + half); columns 0-15 = the 16 channels at tap 2s, columns 16-31 = the same
-                // channels at tap 2s + 1 of this wave (an odd tap count leaves the last slot's upper half on a repeat that is not flushed)
-                const int kk0 = TAPSPLIT ? 0 : wave * 32;
-                const int kk1 = TAPSPLIT ? 128 : wave * 32 + 32;
-                const int col = lane & 31;
-                int toff2[NACC];
-    #pragma unroll
-                for (int s_ = 0; s_ < NACC; ++s_)
-                    toff2[s_] = ((col >= 16 && 2 * s_ + 1 < TPW) ? tapoff[(2 * s_ + 1 < TPW) ? 2 * s_ + 1 : 0] : tapoff[2 * s_]) + (col & 15) * 4 +
-                                ((PAIRC && has2 && col >= 16) ? 256 * XP : 0);
-                // operands of k-step kk + 1 are read from LDS before the MFMAs of k-step kk are issued (one wave per SIMD: nothing else
-                // covers the ~100 cycles of a dependent ds_read in front of every 5 MFMAs)
-                auto rd = [&](int kk, float& av, float (&bv)[NACC]) {
-                    const int pp = 2 * kk + half;
-                    const int pw = pp & (p.TW - 1), ph = (pp >> p.lgTW) & (p.TH - 1), pd = pp >> (p.lgTW + p.lgTH);
-                    av = *reinterpret_cast<const float*>(dyt + pp * DYP + ((col * 4) ^ dy_swz(pp)));
-                    const int xr = ((pd * p.IH + ph * p.sh) * p.IW + pw * p.sw) * XP;
-    #pragma unroll
-                    for (int s_ = 0; s_ < NACC; ++s_) bv[s_] = *reinterpret_cast<const float*>(halo + xr + toff2[s_]);
-                };
-                float av0, bv0[NACC], av1, bv1[NACC];
-                rd(kk0, av0, bv0);
-                for (int kk = kk0; kk < kk1; kk += 2) {        // (kk1 - kk0 is 32 or 128: even)
-                    rd(kk + 1, av1, bv1);
-    #pragma unroll
-                    for (int s_ = 0; s_ < NACC; ++s_) acc[s_][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv0[s_], acc[s_][0], 0, 0, 0);
-                    rd(min(kk + 2, kk1 - 1), av0, bv0);
-    #pragma unroll
-                    for (int s_ = 0; s_ < NACC; ++s_) acc[s_][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv1[s_], acc[s_][0], 0, 0, 0);
-                }
+                f32_tile(halo, dyt, [](auto) {});
             }
         }
 
@@ -943,7 +990,7 @@ static int wgrad_impl(const rho_conv_desc* dp, const void* dy, int64_t dy_width,
     k.xcd_map = (xcd_env && splits % 8 == 0 && (long long)splits * pairs < (1LL << 31)) ? 1 : 0;
     const int maxp = cdiv(t.NP, 64);
     size_t lds = (size_t)(maxp <= 10 ? 10 : 28) * 64 * XP + 256 * DYP;
-    if (d.dtype == RHO_BF16 && maxp <= 10 && !d.pre_a) lds *= 2;     // LDS-DMA path: double-buffered tiles (2 x 72 KB)
+    if (maxp <= 10 && !d.pre_a) lds *= 2;     // LDS-DMA path (both dtypes since round 3): double-buffered tiles (2 x 72 KB)
     hipStream_t st = as_stream(stream);
     if (d.dtype == RHO_BF16) return launch_wgrad_taps<bf16_raw>(d, k, maxp, grid, lds, st);
     return launch_wgrad_taps<float>(d, k, maxp, grid, lds, st);
