@@ -237,3 +237,29 @@ def test_spherical_harmonic_dataset_to_hdf5_and_replay(tmp_path):
     loss = ddpm.training_step(data)
     loss.backward()
     assert torch.isfinite(loss)
+
+
+# ----------------------------------------------------------------------------- the headline geometry against the oracle, whole network
+def test_c3_whole_network_forward_vs_oracle_at_64_cubed():
+    """BASELINE configs[2]'s network (3-D 64^3, mc = 64: 166.8 M parameters, T = 4096 attention) at batch 1 against the CPU oracle
+    on the same weights and input - the whole forward at the benchmarked geometry, not a small-grid stand-in: exact-f32 engine
+    rel-L2 <= 1e-4, bf16 engine <= 3e-2; and sample independence at batch 2 (per-sample GroupNorm / attention, layers.py:71-74)."""
+    model = _bench_unet(3, 64, 64, "fp32", False)
+    x = det_normal((2, 1, 64, 64, 64), "r3c3x")
+    t = torch.tensor([741, 12])
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    cfg = dict(data_shape=[64, 64, 64], in_channels=1, out_channels=1, model_channels=64, num_res_blocks=2, channel_mult=(1, 2, 4, 8),
+               attention_resolutions=[16, 8], num_heads=4, use_scale_shift_norm=True, dims=3, activation="SiLU")
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        ref = R.unet_forward(sd, cfg, x[:1], t[:1])
+        p32 = model(x[:1].to(DEV), t[:1].to(DEV))
+        e32 = rel_l2(p32, ref)
+        model._engines.clear()
+        torch.cuda.empty_cache()
+        model.set_compute_dtype("bf16")
+        pbf = model(x.to(DEV), t.to(DEV))
+        pbf0 = model(x[:1].to(DEV).contiguous(), t[:1].to(DEV))
+    ebf = rel_l2(pbf[:1], ref)
+    assert e32 < 1e-4 and ebf < 3e-2, (e32, ebf)
+    assert rel_l2(pbf[:1], pbf0) < 2e-3           # the same sample alone (fused-statistics tiles are summed in another order)
