@@ -27,6 +27,11 @@
 // Taps per workgroup barrier of the 8-wave M16 variant (with the tap order pinned, see RHO_FENCE: 3 is 3 % faster than 1; the
 // LDS weight ring is 9 slots deep then).  The host sizes the ring with the same constant.
 #define RHO_GB_WIDE 3
+// ... and on the 32-cout variant (4 MFMAs per tap and wave = 128 MFMA cycles between barriers; round 3, c5's mc = 32 levels: conv3
+// 17.5 -> 17.1 ms per sampling step in a same-box A/B, gpurun_out/ab2_*; 0 = a barrier per tap)
+#ifndef RHO_GB_BM32
+#define RHO_GB_BM32 1
+#endif
 
 struct ConvK {
     const char* x1;
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
     // measured on the 8-wave 128-cout variant: GB = 3, R = 9 is 3 % SLOWER than a barrier per tap (131 vs 127 ms per
     // c3 step) - the per-tap barrier is not what limits this kernel - so GB stays 1.
     // (the slot of a step is st % RS: the ring depth must divide the taps of a chunk - 9 | 27 and 9 | 9, not the 3 taps of 1-D)
-    constexpr int GB = (BM == 128 && NW == 8 && M16 && NS % 9 == 0) ? RHO_GB_WIDE : 1;
+    constexpr int GB = (NS % 9 == 0 && ((BM == 128 && NW == 8 && M16) || (RHO_GB_BM32 && BM == 32 && !M16))) ? RHO_GB_WIDE : 1;
     constexpr int RS = (GB == 3) ? 9 : 3;          // LDS ring slots
     constexpr int DS = GB + 1;                     // store distance
     constexpr int LD = DS + 2;                     // load distance
@@ -1213,7 +1218,7 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
     const size_t lds_cap = 160 * 1024;
     const int taps = d.kd * d.kh * d.kw;
     const bool m16 = d.dtype == RHO_BF16 && taps > 1 && taps % 3 == 0 && d.sh == 1 && d.sw == 1 && !d.up_h && !d.up_w;
-    const int WSLOTS = (taps % 3 == 0) ? ((BM == 128 && RHO_GB_WIDE == 3 && m16 && taps % 9 == 0) ? 9 : 3) : 2;   // LDS weight-ring depth (matches the kernel's PIPE / RS)
+    const int WSLOTS = (taps % 3 == 0) ? ((((BM == 128 && m16) || (RHO_GB_BM32 && BM == 32)) && RHO_GB_WIDE == 3 && taps % 9 == 0) ? 9 : 3) : 2;   // LDS weight-ring depth (matches the kernel's PIPE / RS)
     int np_cap = (int)((lds_cap - (size_t)WSLOTS * BM * PITCH) / PITCH);
     if (np_cap > 28 * 64) np_cap = 28 * 64;
     // prefer the small-halo (2 blocks / CU) configuration when it exists
