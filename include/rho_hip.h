@@ -37,7 +37,7 @@ extern "C" {
 /* ABI version: bumped on ANY signature / struct-layout change (2: table_len in rho_q_sample(_coef), fmt in rho_gn_bwd_finalize,
  * rho_conv_desc grew; 3: round-3 additions).  A loader must compare rho_abi_version() with the header it was written against
  * before calling anything else (hip.py does; a build with all symbols but older signatures would be called with shifted arguments). */
-#define RHO_ABI_VERSION 3
+#define RHO_ABI_VERSION 4
 int rho_abi_version(void);
 /* static string: target arch + build flags */
 const char* rho_build_info(void);
@@ -222,6 +222,13 @@ typedef struct rho_conv_desc {
     int32_t gnb_silu;      /* act = SiLU (else identity) */
     const float* gnb_a;    /* [N][split] folded affine of the forward prologue (pre_a / pre_b of the forward conv) */
     const float* gnb_b;
+    /* --- k-split of launches too small to fill the chip (2-D / 1-D layers at low resolution: 1024 positions x 512 couts are 16
+     * workgroups on 256 CUs).  With a workspace the launch is split over the input-channel chunks into up to 16 partial launches
+     * (grid z) whose fp32 tiles land in `ws` and are added in split order, with bias / residuals / rounding, by a second kernel
+     * (reproducible; the partial sums are fp32 either way).  ws = NULL: never split.  rho_conv_workspace_bytes(desc) is the size
+     * the preferred split wants (0: this launch is not split); a smaller workspace lowers the split count. */
+    void* ws;
+    int64_t ws_bytes;
 } rho_conv_desc;
 
 /* n-D convolution, zero padding k/2, as an LDS-halo-staged implicit GEMM on MFMA.
@@ -254,6 +261,11 @@ int rho_prep_conv_weight_sel(const float* w, void* out, int dtype, int64_t cout,
  * statistics are not available for this geometry (channel-major outputs, tiles that straddle samples: 1-D / 2-D
  * kernels, 1x1x1 with positions-per-sample not a multiple of 256); callers then fall back to rho_gn_partial. */
 int64_t rho_conv_stats_tiles(const rho_conv_desc* desc);
+
+/* Workspace the k-split of `desc` wants (rho_conv_desc.ws), in bytes; 0 when the launch would not be split (3-D and 1x1x1 kernels,
+ * phased / channel-major outputs, grids that already fill the chip).  Depends on geometry only: one allocation of the maximum over
+ * a plan's descriptors serves all of them (launches on one stream are ordered). */
+int64_t rho_conv_workspace_bytes(const rho_conv_desc* desc);
 
 /* Test / profiling aid: the name of the kernel instantiation rho_conv_nd_fwd would launch for `desc`
  * ("k_conv<bf16,3,3,3,BM=128,MAXP=5,NW=8,M16=1>"), written NUL-terminated into buf (cap >= 64).  Nothing is launched.

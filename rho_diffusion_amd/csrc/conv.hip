@@ -75,6 +75,12 @@ struct ConvK {
     const float* gnb_a;
     const float* gnb_b;
     int gnb_c1, gnb_silu;
+    // Split-K (small grids, rho_conv_desc.ws): blockIdx.z = k-split s of ksplit; the split contracts the input-channel chunks
+    // [nck * s / ksplit, nck * (s + 1) / ksplit) and stores its fp32 partial tile to slab[s] ([positions][coutp]); k_splitk_reduce
+    // adds the slabs, the bias, the residuals and rounds once
+    int ksplit;
+    float* slab;
+    long long slab_stride;      // floats per split
 };
 
 // floor(a / d) for 0 <= a < 2^20 with inv = 1.0f / d: (a + 0.5) * inv is at least 0.5 / d away from an integer, the
@@ -164,7 +170,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
     const int th_i = (bt / p.tiles_w) % p.tiles_h;
     const int td_i = bt / (p.tiles_w * p.tiles_h);
     const int co0 = ct * BM;
-    const int n = blockIdx.z;
+    const bool splitk = (KD != 3) && (KD * KH * KW > 1) && p.ksplit > 1;            // (2-D / 1-D launches have gridDim.z = 1 otherwise: z carries the k-split)
+    const int n = splitk ? 0 : (int)blockIdx.z;
     const int od0 = td_i * p.TD, oh0 = th_i * p.TH, ow0 = tw_i * p.TW;
     const int gd_base = od0 - (KD / 2);
     const int gh_base = p.up_h ? (oh0 / 2 - 1) : (oh0 * p.sh - p.pad_h);
@@ -237,7 +244,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][j][r] = 0.0f;
 
-    const int nck = p.cin / CK;
+    int ck_lo = 0, nck = p.cin / CK;
+    if (splitk) {
+        const int nall = nck, kz = (int)blockIdx.z;
+        ck_lo = (int)((long long)nall * kz / p.ksplit);
+        nck = (int)((long long)nall * (kz + 1) / p.ksplit) - ck_lo;       // >= 1: the host keeps ksplit <= chunks
+    }
     const size_t wrow_bytes = (size_t)p.cin * sizeof(T);
 
     // weight tile: BM rows x 4 pieces of 16 B; thread -> row (tid>>2) + 64*k, piece tid&3.
@@ -245,7 +257,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
     const bool w_active = (BM >= RPP) || (tid < BM * 4);
     // address = uniform 64-bit base (tap, chunk, cout tile: scalar ALU) + one 32-bit per-thread offset, the `saddr` form of
     // global_load: per-tap 64-bit pointers in VGPRs (27 taps x 2 registers, hoisted out of the chunk loop) spilled to scratch
-    const char* const w_src0 = p.w + (size_t)co0 * wrow_bytes;
+    const char* const w_src0 = p.w + (size_t)co0 * wrow_bytes + (size_t)ck_lo * 64;      // (a chunk is 64 bytes of every weight row)
     // (re-declared opaque at every chunk: otherwise base + tap * stride + offset is hoisted as 27 per-lane 64-bit pointers anyway)
     unsigned w_voff = (unsigned)(tid >> 2) * (unsigned)wrow_bytes + (unsigned)piece * 16u;         // < 128 rows x 16 KiB
     const size_t w_tap_stride = (size_t)p.coutp * wrow_bytes;
@@ -348,7 +360,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
     constexpr int TPF = (NT > 6) ? NT - 6 : 0;        // tap at which the next chunk's loads are issued
     uint4 hv[HPF ? MAXP : 1];
     auto halo_src = [&](int ck_, const char*& src, int& cs, int& csrc) {
-        const int c = ck_ * CK;
+        const int c = (ck_lo + ck_) * CK;
         if (c < p.c1) { src = p.x1; cs = p.c1; csrc = c; } else { src = p.x2; cs = p.c2; csrc = c - p.c1; }
     };
 #define RHO_HALO_LOAD(ck_)                                                                                         \
@@ -369,7 +381,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
         // ---- stage the halo tile of this channel chunk (previous chunk's reads are fenced by the
         //      barrier that closed its last tap)
         {
-            const int c = ck * CK;
+            const int c = (ck_lo + ck) * CK;
             if constexpr (HPF) {
 #pragma unroll
                 for (int i = 0; i < MAXP; ++i) {
@@ -779,6 +791,34 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
     const __attribute__((address_space(4))) ConvK& q = *qp;
     // ---- epilogue: lane holds, for position column (lane&31) of tile j, channels
     //      co0 + 32*mi + 8*rg + 4*half + {0,1,2,3}  in acc[mi][j][4*rg + {0..3}]
+    if (splitk) {
+        // k-split launch: the raw fp32 partial sums of this split go to its slab ([positions][split], the host only splits launches
+        // whose whole output is channels-last, unphased); bias, residuals and the rounding happen once, in k_splitk_reduce
+        float* const slab = q.slab + (size_t)blockIdx.z * q.slab_stride;
+#pragma unroll
+        for (int jx = 0; jx < (M16 ? 4 : 2); ++jx) {
+            const int pp = M16 ? tile_position16(wpos * 4 + jx, lane & 15, q.TW, q.pair_lg) : tile_position(wpos * 2 + jx, lane & 31, q.TW, q.pair_lg);
+            const int pw = pp & (q.TW - 1);
+            const int ph = (pp >> q.lgTW) & (q.TH - 1);
+            const int pd = pp >> (q.lgTW + q.lgTH);
+            const int od = od0 + pd, oh = oh0 + ph, ow = ow0 + pw;
+            if (od >= q.Do || oh >= q.Ho || ow >= q.Wo) continue;
+            const size_t L = ((size_t)od * q.Ho + oh) * q.Wo + ow;
+            const int j = M16 ? (jx >> 1) : jx;
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+#pragma unroll
+                for (int rx = 0; rx < (M16 ? 2 : 4); ++rx) {
+                    const int rg = M16 ? 2 * rx + (jx & 1) : rx;
+                    const int co = M16 ? co0 + wco * (BM / WCO) + 16 * (2 * mi + rx) + 4 * (lane >> 4)
+                                       : co0 + wco * (BM / WCO) + mi * 32 + rg * 8 + half * 4;
+                    *reinterpret_cast<float4*>(slab + L * q.split + co) =
+                        make_float4(acc[mi][j][rg * 4 + 0], acc[mi][j][rg * 4 + 1], acc[mi][j][rg * 4 + 2], acc[mi][j][rg * 4 + 3]);
+                }
+            }
+        }
+        return;
+    }
     const bool cl_region = (co0 < q.split);
     if (cl_region) {
         // Channels-last output (every block of this launch region: BM divides split).  The accumulator layout gives a
@@ -1052,6 +1092,45 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
     }
 }
 
+// Second half of a k-split conv: y[L][co] = round( sum_s slab[s][L][co] + bias[co] + res_add[sample(L)][co] + res[L][co] ), the
+// slabs added in split order (fixed => reproducible), the same operand order as the fused epilogue after the contraction.
+template <typename T>
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ slab, long long slab_stride, int ksplit, long long positions,
+                                                       int cout, const float* __restrict__ bias, const float* __restrict__ res_add,
+                                                       long long res_add_stride, long long S_out, const char* __restrict__ res, char* __restrict__ y) {
+    const int c4 = cout / 4;
+    const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (item >= positions * c4) return;
+    const long long L = item / c4;
+    const int co = (int)(item - L * c4) * 4;
+    const size_t eo = (size_t)L * cout + co;
+    float4 a = *reinterpret_cast<const float4*>(slab + eo);
+    for (int s = 1; s < ksplit; ++s) {
+        const float4 b = *reinterpret_cast<const float4*>(slab + (size_t)s * slab_stride + eo);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const float4 bv = *reinterpret_cast<const float4*>(bias + co);
+    float v0 = a.x + bv.x, v1 = a.y + bv.y, v2 = a.z + bv.z, v3 = a.w + bv.w;
+    if (res_add != nullptr) {
+        const float4 e = *reinterpret_cast<const float4*>(res_add + (L / S_out) * res_add_stride + co);
+        v0 += e.x; v1 += e.y; v2 += e.z; v3 += e.w;
+    }
+    if constexpr (sizeof(T) == 2) {
+        if (res != nullptr) {
+            const uint2 r = *reinterpret_cast<const uint2*>(res + eo * 2);
+            v0 += __uint_as_float(r.x << 16); v1 += __uint_as_float(r.x & 0xFFFF0000u);
+            v2 += __uint_as_float(r.y << 16); v3 += __uint_as_float(r.y & 0xFFFF0000u);
+        }
+        *reinterpret_cast<uint2*>(y + eo * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+    } else {
+        if (res != nullptr) {
+            const float4 r = *reinterpret_cast<const float4*>(res + eo * 4);
+            v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
+        }
+        *reinterpret_cast<float4*>(y + eo * 4) = make_float4(v0, v1, v2, v3);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ host
 namespace {
 
@@ -1129,7 +1208,7 @@ int launch_taps(const rho_conv_desc& d, const ConvK& k, int BM, int np, dim3 gri
 
 }  // namespace
 
-static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles) {
+static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles, int64_t* ws_want = nullptr) {
     if (!dp) return RHO_E_ARG;
     const rho_conv_desc& d = *dp;
     if (!d.x1 || !d.w || !d.bias) return RHO_E_ARG;
@@ -1263,6 +1342,27 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
         else if (taps == 1 && k.S_out % 256 == 0 && t.TW == 256) tps = k.S_out / 256;
     }
     if (stats_tiles) { *stats_tiles = tps; return 0; }
+    // k-split (rho_conv_desc.ws): merged-batch launches (2-D / 1-D kernels with taps) whose grid leaves most CUs idle
+    int ksplit = 1;
+    const long long positions = (long long)k.Do * k.Ho * k.Wo;
+    {
+        const long long wgs = tiles * (d.coutp / BM);
+        const int chunks = cin / CK;
+        static const bool split_env = !(getenv("RHO_CONV_SPLITK") && atoi(getenv("RHO_CONV_SPLITK")) == 0);
+        if (split_env && d.kd == 1 && taps > 1 && d.split == d.cout && !d.ph_h && !d.ph_w && !d.stats && wgs <= 128 && chunks >= 4) {
+            int want = (int)(512 / wgs);                               // about two workgroups per CU
+            if (want > 16) want = 16;
+            if (want > chunks / 2) want = chunks / 2;                  // >= 2 chunks per split: the set-up of a tile is paid per split
+            if (ws_want) { *ws_want = want >= 2 ? (int64_t)want * positions * d.cout * (int64_t)sizeof(float) : 0; return 0; }
+            if (d.ws != nullptr && want >= 2) {
+                const long long fit = d.ws_bytes / (positions * d.cout * (long long)sizeof(float));
+                if (fit < want) want = (int)fit;
+                if (want >= 2) ksplit = want;
+            }
+        } else if (ws_want) { *ws_want = 0; return 0; }
+    }
+    k.ksplit = ksplit; k.slab = (float*)d.ws; k.slab_stride = positions * d.cout;
+    if (ksplit > 1) grid.z = (unsigned)ksplit;
     k.stats = nullptr; k.tps = 1;
     if (d.stats) {
         if (tps <= 0) return RHO_E_ARG;
@@ -1290,8 +1390,24 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
     if (d.split > 0 && lds < lds_epi) lds = lds_epi;
     hipStream_t st = as_stream(stream);
     static const bool m16_env = !(getenv("RHO_CONV_M16") && atoi(getenv("RHO_CONV_M16")) == 0);
-    if (d.dtype == RHO_BF16) return launch_taps<bf16_raw>(d, k, BM, t.NP, grid, lds, m16 && m16_env, st);
-    return launch_taps<float>(d, k, BM, t.NP, grid, lds, false, st);
+    const int rc = d.dtype == RHO_BF16 ? launch_taps<bf16_raw>(d, k, BM, t.NP, grid, lds, m16 && m16_env, st)
+                                       : launch_taps<float>(d, k, BM, t.NP, grid, lds, false, st);
+    if (rc != 0 || ksplit == 1 || g_variant != nullptr) return rc;
+    const long long items = positions * (d.cout / 4);
+    const dim3 rgrid((unsigned)((items + 255) / 256));
+    if (d.dtype == RHO_BF16)
+        hipLaunchKernelGGL(k_splitk_reduce<bf16_raw>, rgrid, dim3(256), 0, st, k.slab, k.slab_stride, ksplit, positions, d.cout, d.bias, d.res_add,
+                           (long long)k.res_add_stride, k.S_out, (const char*)d.res, (char*)d.y);
+    else
+        hipLaunchKernelGGL(k_splitk_reduce<float>, rgrid, dim3(256), 0, st, k.slab, k.slab_stride, ksplit, positions, d.cout, d.bias, d.res_add,
+                           (long long)k.res_add_stride, k.S_out, (const char*)d.res, (char*)d.y);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int64_t rho_conv_workspace_bytes(const rho_conv_desc* dp) {
+    int64_t b = 0;
+    return conv_impl(dp, nullptr, nullptr, &b) == 0 ? b : 0;
 }
 
 extern "C" int rho_conv_nd_fwd(const rho_conv_desc* dp, void* stream) { return conv_impl(dp, stream, nullptr); }

@@ -346,6 +346,23 @@ def conv_stats_tiles(desc: ConvDesc) -> int:
     return int(hip.lib().rho_conv_stats_tiles(C.byref(desc)))
 
 
+def conv_workspace_bytes(desc: ConvDesc) -> int:
+    """Bytes of workspace the k-split of ``desc`` wants (rho_conv_desc.ws); 0: the launch is not split."""
+    return int(hip.lib().rho_conv_workspace_bytes(C.byref(desc)))
+
+
+def attach_conv_workspace(descs, device) -> Optional[Tensor]:
+    """One workspace for all of ``descs`` (stream-ordered launches share it): the largest any of them wants, or None."""
+    want = [conv_workspace_bytes(d) for d in descs]
+    if not want or max(want) == 0:
+        return None
+    ws = torch.empty(max(want), dtype=torch.uint8, device=device)
+    for d, b in zip(descs, want):
+        if b:
+            d.ws, d.ws_bytes = ptr(ws), ws.numel()
+    return ws
+
+
 def conv_variant(desc: ConvDesc) -> str:
     """Name of the k_conv instantiation rho_conv_nd_fwd launches for ``desc`` (nothing is launched)."""
     buf = C.create_string_buffer(128)
@@ -375,6 +392,7 @@ def conv(x1: Tensor, x2: Optional[Tensor], w: Tensor, bias: Tensor, *, kernel, c
         y2 = torch.empty(N, cout - split, Do * Ho * Wo, dtype=y2_dtype or x1.dtype, device=x1.device)
     d = make_conv_desc(x1, x2, w, bias, kernel=kernel, cout=cout, split=split, y=y, y2=y2, stride_hw=stride_hw, up_hw=up_hw,
                        pre_a=pre_a, pre_b=pre_b, pre_silu=pre_silu, res=res, res_add=res_add, res_add_stride=res_add_stride)
+    ws = attach_conv_workspace([d], x1.device)      # (freed to the caching allocator on return: reuse is ordered on this stream)
     conv_launch(d)
     return y, y2
 

@@ -768,6 +768,10 @@ class _Plan:
         self.bwd_marks: List[Tuple[int, List[nn.Parameter]]] = []   # after bwd[:i] these parameters' gradients are final
         if train:
             self._build_backward()
+        # k-split of the small-grid 2-D / 1-D launches (rho_conv_desc.ws): one workspace per plan, shared by its ordered launches
+        ws = ops.attach_conv_workspace(self.fwd_descs, dev)
+        if ws is not None:
+            self.keep.append(ws)
 
     # ------------------------------------------------------------------ backward construction
     def _build_backward(self) -> None:
