@@ -170,7 +170,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
     const int th_i = (bt / p.tiles_w) % p.tiles_h;
     const int td_i = bt / (p.tiles_w * p.tiles_h);
     const int co0 = ct * BM;
-    const bool splitk = (KD != 3) && (KD * KH * KW > 1) && p.ksplit > 1;            // (2-D / 1-D launches have gridDim.z = 1 otherwise: z carries the k-split)
+    const bool splitk = (KD != 3) && p.ksplit > 1;            // (2-D / 1-D launches have gridDim.z = 1 otherwise: z carries the k-split)
     const int n = splitk ? 0 : (int)blockIdx.z;
     const int od0 = td_i * p.TD, oh0 = th_i * p.TH, ow0 = tw_i * p.TW;
     const int gd_base = od0 - (KD / 2);
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
         auto issue = [&](auto SET, int ckk) {
             constexpr int S_ = decltype(SET)::value;
             const int cc = min(ckk, nck - 1);              // clamped: static number of loads in flight (counted vmcnt)
-            const int c = cc * CK;
+            const int c = (ck_lo + cc) * CK;
             const char* src;
             int cs, csrc;
             if (c < p.c1) { src = p.x1; cs = p.c1; csrc = c; } else { src = p.x2; cs = p.c2; csrc = c - p.c1; }
@@ -672,11 +672,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                 if (spos[i] >= 0 && ssmp[i] != smp_ref) mine = false;
             coef_lds = __syncthreads_and(mine ? 1 : 0) != 0;
             if (coef_lds) {
-                const int cpad = nck * CK;
+                const int cpad = nck * CK, cbase = ck_lo * CK;          // (this launch's chunks: all of them unless k-split)
                 for (int i = tid; i < cpad; i += NTHR) {
-                    const bool in = i < p.cin;
-                    coef[i] = in ? p.pre_a[(size_t)smp_ref * p.cin + i] : 0.0f;
-                    coef[cpad + i] = in ? p.pre_b[(size_t)smp_ref * p.cin + i] : 0.0f;
+                    const bool in = cbase + i < p.cin;
+                    coef[i] = in ? p.pre_a[(size_t)smp_ref * p.cin + cbase + i] : 0.0f;
+                    coef[cpad + i] = in ? p.pre_b[(size_t)smp_ref * p.cin + cbase + i] : 0.0f;
                 }
                 __syncthreads();
             }
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                             const float* const ca = coef + c + piece * PE;
                             u = apply_pre<T>(u, ca, ca + nck * CK, p.pre_silu);
                         } else {
-                            const size_t co = (size_t)ssmp[i] * p.cin + c + piece * PE;
+                            const size_t co = (size_t)ssmp[i] * p.cin + ck_lo * CK + c + piece * PE;
                             u = apply_pre<T>(u, p.pre_a + co, p.pre_b + co, p.pre_silu);
                         }
                     }
@@ -792,8 +792,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
     // ---- epilogue: lane holds, for position column (lane&31) of tile j, channels
     //      co0 + 32*mi + 8*rg + 4*half + {0,1,2,3}  in acc[mi][j][4*rg + {0..3}]
     if (splitk) {
-        // k-split launch: the raw fp32 partial sums of this split go to its slab ([positions][split], the host only splits launches
-        // whose whole output is channels-last, unphased); bias, residuals and the rounding happen once, in k_splitk_reduce
+        // k-split launch: the raw fp32 partial sums of this split go to its slab ([launch positions][coutp]; the host only splits
+        // launches whose outputs are all channels-last); bias, residuals and the rounding happen once, in k_splitk_reduce
         float* const slab = q.slab + (size_t)blockIdx.z * q.slab_stride;
 #pragma unroll
         for (int jx = 0; jx < (M16 ? 4 : 2); ++jx) {
@@ -812,7 +812,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                     const int rg = M16 ? 2 * rx + (jx & 1) : rx;
                     const int co = M16 ? co0 + wco * (BM / WCO) + 16 * (2 * mi + rx) + 4 * (lane >> 4)
                                        : co0 + wco * (BM / WCO) + mi * 32 + rg * 8 + half * 4;
-                    *reinterpret_cast<float4*>(slab + L * q.split + co) =
+                    *reinterpret_cast<float4*>(slab + L * q.coutp + co) =
                         make_float4(acc[mi][j][rg * 4 + 0], acc[mi][j][rg * 4 + 1], acc[mi][j][rg * 4 + 2], acc[mi][j][rg * 4 + 3]);
                 }
             }
@@ -1092,29 +1092,55 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
     }
 }
 
-// Second half of a k-split conv: y[L][co] = round( sum_s slab[s][L][co] + bias[co] + res_add[sample(L)][co] + res[L][co] ), the
+struct SplitMap {          // launch grid position (od, oh, ow) -> output row ((od * Ho_out) + oh * oy_mul + oy_add) * Wo_out + ow * ox_mul + ox_add
+    int Ho, Wo, Ho_out, Wo_out, oy_mul, oy_add, ox_mul, ox_add;      // (identity unless the launch is one sub-pixel phase of its output)
+};
+struct SplitOut {          // the two channels-last output regions of a launch: co < split -> y (+ res, res_add), else y2 (+ res2)
+    int cout, coutp, split;
+    const float* bias;
+    const float* res_add;
+    long long res_add_stride, S_out;
+    const char* res;
+    char* y;
+    const char* res2;
+    char* y2;
+};
+// Second half of a k-split conv: out[L][co] = round( sum_s slab[s][L][co] + bias[co] + res_add[sample(L)][co] + res[L][co] ), the
 // slabs added in split order (fixed => reproducible), the same operand order as the fused epilogue after the contraction.
 template <typename T>
 __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ slab, long long slab_stride, int ksplit, long long positions,
-                                                       int cout, const float* __restrict__ bias, const float* __restrict__ res_add,
-                                                       long long res_add_stride, long long S_out, const char* __restrict__ res, char* __restrict__ y) {
-    const int c4 = cout / 4;
+                                                       SplitOut o, SplitMap m) {
+    const int c4 = o.coutp / 4;
     const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
     if (item >= positions * c4) return;
-    const long long L = item / c4;
-    const int co = (int)(item - L * c4) * 4;
-    const size_t eo = (size_t)L * cout + co;
-    float4 a = *reinterpret_cast<const float4*>(slab + eo);
+    const long long Ls = item / c4;                      // position in the launch's own grid = slab row
+    int co = (int)(item - Ls * c4) * 4;
+    if (co >= o.cout) return;                            // padding columns of the last cout tile (widths are multiples of 4)
+    const size_t so = (size_t)Ls * o.coutp + co;
+    float4 a = *reinterpret_cast<const float4*>(slab + so);
     for (int s = 1; s < ksplit; ++s) {
-        const float4 b = *reinterpret_cast<const float4*>(slab + (size_t)s * slab_stride + eo);
+        const float4 b = *reinterpret_cast<const float4*>(slab + (size_t)s * slab_stride + so);
         a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
-    const float4 bv = *reinterpret_cast<const float4*>(bias + co);
+    long long L = Ls;
+    if (m.oy_mul != 1 || m.ox_mul != 1) {
+        const int ow = (int)(Ls % m.Wo);
+        const long long r = Ls / m.Wo;
+        const int oh = (int)(r % m.Ho);
+        L = ((r / m.Ho) * m.Ho_out + (oh * m.oy_mul + m.oy_add)) * m.Wo_out + (ow * m.ox_mul + m.ox_add);
+    }
+    const float4 bv = *reinterpret_cast<const float4*>(o.bias + co);
     float v0 = a.x + bv.x, v1 = a.y + bv.y, v2 = a.z + bv.z, v3 = a.w + bv.w;
-    if (res_add != nullptr) {
-        const float4 e = *reinterpret_cast<const float4*>(res_add + (L / S_out) * res_add_stride + co);
+    const bool first = co < o.split;
+    if (first && o.res_add != nullptr) {
+        const float4 e = *reinterpret_cast<const float4*>(o.res_add + (L / o.S_out) * o.res_add_stride + co);
         v0 += e.x; v1 += e.y; v2 += e.z; v3 += e.w;
     }
+    const int width = first ? o.split : o.cout - o.split;
+    const char* const res = first ? o.res : o.res2;
+    char* const y = first ? o.y : o.y2;
+    if (!first) co -= o.split;
+    const size_t eo = (size_t)L * width + co;
     if constexpr (sizeof(T) == 2) {
         if (res != nullptr) {
             const uint2 r = *reinterpret_cast<const uint2*>(res + eo * 2);
@@ -1349,19 +1375,20 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
         const long long wgs = tiles * (d.coutp / BM);
         const int chunks = cin / CK;
         static const bool split_env = !(getenv("RHO_CONV_SPLITK") && atoi(getenv("RHO_CONV_SPLITK")) == 0);
-        if (split_env && d.kd == 1 && taps > 1 && d.split == d.cout && !d.ph_h && !d.ph_w && !d.stats && wgs <= 128 && chunks >= 4) {
+        if (split_env && d.kd == 1 && (d.split == d.cout || d.y2_cl) && !d.stats && wgs <= 128 && chunks >= 4) {
             int want = (int)(512 / wgs);                               // about two workgroups per CU
             if (want > 16) want = 16;
-            if (want > chunks / 2) want = chunks / 2;                  // >= 2 chunks per split: the set-up of a tile is paid per split
-            if (ws_want) { *ws_want = want >= 2 ? (int64_t)want * positions * d.cout * (int64_t)sizeof(float) : 0; return 0; }
+            const int per = taps == 1 ? 4 : 2;                         // chunks per split at least: the set-up of a tile is paid per split
+            if (want > chunks / per) want = chunks / per;
+            if (ws_want) { *ws_want = want >= 2 ? (int64_t)want * positions * d.coutp * (int64_t)sizeof(float) : 0; return 0; }
             if (d.ws != nullptr && want >= 2) {
-                const long long fit = d.ws_bytes / (positions * d.cout * (long long)sizeof(float));
+                const long long fit = d.ws_bytes / (positions * d.coutp * (long long)sizeof(float));
                 if (fit < want) want = (int)fit;
                 if (want >= 2) ksplit = want;
             }
         } else if (ws_want) { *ws_want = 0; return 0; }
     }
-    k.ksplit = ksplit; k.slab = (float*)d.ws; k.slab_stride = positions * d.cout;
+    k.ksplit = ksplit; k.slab = (float*)d.ws; k.slab_stride = positions * d.coutp;
     if (ksplit > 1) grid.z = (unsigned)ksplit;
     k.stats = nullptr; k.tps = 1;
     if (d.stats) {
@@ -1393,14 +1420,13 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
     const int rc = d.dtype == RHO_BF16 ? launch_taps<bf16_raw>(d, k, BM, t.NP, grid, lds, m16 && m16_env, st)
                                        : launch_taps<float>(d, k, BM, t.NP, grid, lds, false, st);
     if (rc != 0 || ksplit == 1 || g_variant != nullptr) return rc;
-    const long long items = positions * (d.cout / 4);
+    const long long items = positions * (d.coutp / 4);
     const dim3 rgrid((unsigned)((items + 255) / 256));
-    if (d.dtype == RHO_BF16)
-        hipLaunchKernelGGL(k_splitk_reduce<bf16_raw>, rgrid, dim3(256), 0, st, k.slab, k.slab_stride, ksplit, positions, d.cout, d.bias, d.res_add,
-                           (long long)k.res_add_stride, k.S_out, (const char*)d.res, (char*)d.y);
-    else
-        hipLaunchKernelGGL(k_splitk_reduce<float>, rgrid, dim3(256), 0, st, k.slab, k.slab_stride, ksplit, positions, d.cout, d.bias, d.res_add,
-                           (long long)k.res_add_stride, k.S_out, (const char*)d.res, (char*)d.y);
+    const SplitMap sm{k.Ho, k.Wo, k.Ho_out, k.Wo_out, k.oy_mul, k.oy_add, k.ox_mul, k.ox_add};
+    const SplitOut so{d.cout, d.coutp, d.split, d.bias, d.res_add, (long long)k.res_add_stride, k.S_out, (const char*)d.res, (char*)d.y,
+                      (const char*)d.res2, (char*)d.y2};
+    if (d.dtype == RHO_BF16) hipLaunchKernelGGL(k_splitk_reduce<bf16_raw>, rgrid, dim3(256), 0, st, k.slab, k.slab_stride, ksplit, positions, so, sm);
+    else hipLaunchKernelGGL(k_splitk_reduce<float>, rgrid, dim3(256), 0, st, k.slab, k.slab_stride, ksplit, positions, so, sm);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
