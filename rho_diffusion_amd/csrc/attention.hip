@@ -18,6 +18,20 @@
 
 #include "common.h"
 
+// max / sum of a value over the two half-waves of a column (lanes l and l ^ 32), in every lane: one v_permlane32_swap (gfx950: the
+// operand pair comes back as {x[l & 31], x[(l & 31) + 32]}) instead of a ds_bpermute round trip through the LDS crossbar and the
+// lgkmcnt(0) it drags behind it, which also waits for every LDS read in flight.  Both operations commute: the results are the bits
+// the exchange gave.
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float halves_max(float x) {
+    const u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+}
+__device__ __forceinline__ float halves_sum(float x) {
+    const u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+
 template <int CH, int KT>  // KT keys per LDS tile (64; 32 for CH = 256 to stay inside static LDS)
 __global__ __launch_bounds__(256, CH <= 128 ? 2 : 1) void k_attn_bf16(const bf16_raw* __restrict__ qk, const bf16_raw* __restrict__ vt,
                                                    bf16_raw* __restrict__ out, int T, int C, float scale_log2e,
@@ -117,13 +131,49 @@ __global__ __launch_bounds__(256, CH <= 128 ? 2 : 1) void k_attn_bf16(const bf16
                 *reinterpret_cast<uint4*>(k_lds + key * KP + piece * 16) = (kt0 + key < T) ? kv[i] : make_uint4(0u, 0u, 0u, 0u);
         }
     };
+    // Whole tiles (every tile but a ragged last one) take a path without the clamps, selects and 64-bit multiplies above (~50 of
+    // the ~210 vector instructions per tile and wave at CH = 64, where the softmax already out-issues the matrix cores): the
+    // tile origin is a uniform (scalar) base, the thread's share a 32-bit offset computed once, the LDS addresses likewise.
+    constexpr bool FAST = KEXACT && (VIT * 256 == NCT * 32 * VPC) && (CH % 32 == 0);
+    unsigned koff[KIT], voff[VIT], klds[KIT], vlds[VIT];
+#pragma unroll
+    for (int i = 0; i < KIT; ++i) {
+        const int pc = tid + 256 * i, key = pc / KPC, piece = pc % KPC;
+        koff[i] = (unsigned)(((size_t)key * row2c + piece * 8) * 2);         // bytes; 64 rows of <= 4 K channels
+        klds[i] = (unsigned)(key * KP + piece * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < VIT; ++i) {
+        const int pc = tid + 256 * i, c = pc / VPC, piece = pc % VPC;
+        voff[i] = (unsigned)(((size_t)(c < CH ? c : 0) * T + piece * 8) * 2);  // bytes; CH rows of T <= 2^24 keys
+        vlds[i] = (unsigned)(c * VP + piece * 16);
+    }
+    const bool fast_ok = FAST && vec_v && (size_t)CH * T * 2 < (1ull << 32);
+    auto load_tile_fast = [&](int kt0) {
+        const char* const kt_base = reinterpret_cast<const char*>(kbase) + (size_t)kt0 * row2c * 2;
+        const char* const vt_base = reinterpret_cast<const char*>(vbase) + (size_t)kt0 * 2;
+#pragma unroll
+        for (int i = 0; i < KIT; ++i) kv[i] = *reinterpret_cast<const uint4*>(kt_base + koff[i]);
+#pragma unroll
+        for (int i = 0; i < VIT; ++i) vv[i] = *reinterpret_cast<const uint4*>(vt_base + voff[i]);
+    };
+    auto store_tile_fast = [&]() {
+#pragma unroll
+        for (int i = 0; i < VIT; ++i) *reinterpret_cast<uint4*>(v_lds + vlds[i]) = vv[i];
+#pragma unroll
+        for (int i = 0; i < KIT; ++i) *reinterpret_cast<uint4*>(k_lds + klds[i]) = kv[i];
+    };
     load_tile(0);
     store_tile(0);
     __syncthreads();
 
     for (int kt0 = 0; kt0 < T; kt0 += KT) {
         const bool more = kt0 + KT < T;
-        if (more) load_tile(kt0 + KT);               // in flight under this tile's MFMAs
+        const bool next_whole = fast_ok && kt0 + 2 * KT <= T;      // (uniform)
+        if (more) {                                  // in flight under this tile's MFMAs
+            if (next_whole) load_tile_fast(kt0 + KT);
+            else load_tile(kt0 + KT);
+        }
 
         // ---- S^T for the 32-key sub-tiles
         f32x16_t s[NU];
@@ -162,7 +212,7 @@ __global__ __launch_bounds__(256, CH <= 128 ? 2 : 1) void k_attn_bf16(const bf16
         for (int u = 0; u < NU; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[u][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = halves_max(mx);
         const float m_new = fmaxf(m_run, mx * sc);          // sc > 0: max commutes with the scaling
         // the running maximum stops moving after the first few tiles: rescale only when some query of this wave
         // saw a new maximum (alpha == 1 exactly otherwise, so skipping is bit-identical)
@@ -184,7 +234,7 @@ __global__ __launch_bounds__(256, CH <= 128 ? 2 : 1) void k_attn_bf16(const bf16
                 s[u][r] = pv;
                 ps += pv;
             }
-        ps += __shfl_xor(ps, 32, 64);
+        ps = halves_sum(ps);
         l_run += ps;
 
         // ---- O^T += V^T * P^T : P accumulator registers 8s..8s+7 are k-step s of the B operand
@@ -206,7 +256,8 @@ __global__ __launch_bounds__(256, CH <= 128 ? 2 : 1) void k_attn_bf16(const bf16
             }
         if (more) {
             __syncthreads();                         // this tile's LDS fragments are consumed by every wave
-            store_tile(kt0 + KT);
+            if (next_whole) store_tile_fast();
+            else store_tile(kt0 + KT);
             __syncthreads();
         }
     }
@@ -401,7 +452,7 @@ __global__ __launch_bounds__(256) void k_attn_f32m(const float* __restrict__ qk,
         for (int u = 0; u < NU; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[u][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = halves_max(mx);
         const float m_new = fmaxf(m_run, mx * sc);
         if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
             const float alpha = exp2f(m_run - m_new);
@@ -421,7 +472,7 @@ __global__ __launch_bounds__(256) void k_attn_f32m(const float* __restrict__ qk,
                 s[u][r] = pv;
                 ps += pv;
             }
-        ps += __shfl_xor(ps, 32, 64);
+        ps = halves_sum(ps);
         l_run += ps;
 #pragma unroll
         for (int u = 0; u < NU; ++u)
