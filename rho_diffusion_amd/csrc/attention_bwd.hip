@@ -157,49 +157,94 @@ __global__ __launch_bounds__(256, CH <= 128 ? 2 : 1) void k_attn_dq(const bf16_r
     const bf16_raw* const kbase = qk + (size_t)b * T * row2c + C + (size_t)h * CH;
     const bf16_raw* const vbase = vt + ((size_t)b * C + (size_t)h * CH) * T;
 
-    for (int kt0 = 0; kt0 < T; kt0 += KT) {
-        __syncthreads();
-        {
-            uint4 kv[KIT];
+    // K / V^T tiles are loaded, waited for and written between the two barriers (PRE = false).  Fetching tile t + 1 under the MFMAs
+    // of tile t (T14, as the forward kernel does) needs 16 more registers: CH = 64 then drops from three waves per SIMD to two and
+    // measures 0.8 % slower (c5 shape), CH = 128 already uses all 256.  Whole tiles (all but a ragged last one) use a scalar tile
+    // origin + per-thread 32-bit offsets computed once instead of clamps, selects and 64-bit multiplies per tile.
+    constexpr bool PRE = false;
+    constexpr bool FAST = KEXACT && VEXACT && (CH % 32 == 0);
+    uint4 kv[KIT], vv[VIT];
+    unsigned koff[KIT], voff[VIT], klds[KIT], vlds[VIT];
 #pragma unroll
-            for (int i = 0; i < KIT; ++i) {
+    for (int i = 0; i < KIT; ++i) {
+        const int pc = tid + 256 * i, key = pc / KPC, piece = pc % KPC;
+        koff[i] = (unsigned)(((size_t)key * row2c + piece * 8) * 2);
+        klds[i] = (unsigned)KL::at(key, piece * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < VIT; ++i) {
+        const int pc = tid + 256 * i, c = pc / VPC, piece = pc % VPC;
+        voff[i] = (unsigned)(((size_t)(c < CH ? c : 0) * T + piece * 8) * 2);
+        vlds[i] = (unsigned)(c * VP + piece * 16);
+    }
+    const bool fast_ok = FAST && vec_v && (size_t)CH * T * 2 < (1ull << 32);
+    auto load_kv = [&](int kt0) {
+        if (fast_ok && kt0 + KT <= T) {                     // (uniform)
+            const char* const kb = reinterpret_cast<const char*>(kbase) + (size_t)kt0 * row2c * 2;
+            const char* const vb = reinterpret_cast<const char*>(vbase) + (size_t)kt0 * 2;
+#pragma unroll
+            for (int i = 0; i < KIT; ++i) kv[i] = *reinterpret_cast<const uint4*>(kb + koff[i]);
+#pragma unroll
+            for (int i = 0; i < VIT; ++i) vv[i] = *reinterpret_cast<const uint4*>(vb + voff[i]);
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < KIT; ++i) {
+            const int pc = tid + 256 * i;
+            const int key = KEXACT ? pc / KPC : min(pc / KPC, KT - 1), piece = pc % KPC;
+            kv[i] = *reinterpret_cast<const uint4*>(kbase + (size_t)min(kt0 + key, T - 1) * row2c + piece * 8);
+        }
+        if (vec_v) {
+#pragma unroll
+            for (int i = 0; i < VIT; ++i) {
                 const int pc = tid + 256 * i;
-                const int key = KEXACT ? pc / KPC : min(pc / KPC, KT - 1), piece = pc % KPC;
-                kv[i] = *reinterpret_cast<const uint4*>(kbase + (size_t)min(kt0 + key, T - 1) * row2c + piece * 8);
-            }
-            if (vec_v) {
-                uint4 vv[VIT];
-#pragma unroll
-                for (int i = 0; i < VIT; ++i) {
-                    const int pc = tid + 256 * i;
-                    const int c = pc / VPC, piece = pc % VPC;
-                    const bool ok = (VEXACT || pc < NCT * 32 * VPC) && c < CH && kt0 + piece * 8 < T;
-                    vv[i] = *reinterpret_cast<const uint4*>(vbase + (size_t)(ok ? c : 0) * T + (ok ? kt0 + piece * 8 : 0));
-                    if (!ok) vv[i] = make_uint4(0u, 0u, 0u, 0u);
-                }
-#pragma unroll
-                for (int i = 0; i < VIT; ++i) {
-                    const int pc = tid + 256 * i;
-                    const int c = pc / VPC, piece = pc % VPC;
-                    if (VEXACT || pc < NCT * 32 * VPC) *reinterpret_cast<uint4*>(v_lds + c * VP + piece * 16) = vv[i];
-                }
-            } else {
-                for (int e = tid; e < NCT * 32 * KT; e += 256) {
-                    const int c = e / KT, key = e % KT;
-                    bf16_raw v = 0;
-                    if (c < CH && kt0 + key < T) v = vbase[(size_t)c * T + kt0 + key];
-                    *reinterpret_cast<bf16_raw*>(v_lds + c * VP + key * 2) = v;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < KIT; ++i) {
-                const int pc = tid + 256 * i;
-                const int key = pc / KPC, piece = pc % KPC;
-                if (KEXACT || pc < KT * KPC)
-                    *reinterpret_cast<uint4*>(k_lds + KL::at(key, piece * 16)) = (kt0 + key < T) ? kv[i] : make_uint4(0u, 0u, 0u, 0u);
+                const int c = pc / VPC, piece = pc % VPC;
+                const bool ok = (VEXACT || pc < NCT * 32 * VPC) && c < CH && kt0 + piece * 8 < T;
+                vv[i] = *reinterpret_cast<const uint4*>(vbase + (size_t)(ok ? c : 0) * T + (ok ? kt0 + piece * 8 : 0));
             }
         }
+    };
+    auto store_kv = [&](int kt0) {
+        if (fast_ok && kt0 + KT <= T) {
+#pragma unroll
+            for (int i = 0; i < VIT; ++i) *reinterpret_cast<uint4*>(v_lds + vlds[i]) = vv[i];
+#pragma unroll
+            for (int i = 0; i < KIT; ++i) *reinterpret_cast<uint4*>(k_lds + klds[i]) = kv[i];
+            return;
+        }
+        if (vec_v) {
+#pragma unroll
+            for (int i = 0; i < VIT; ++i) {
+                const int pc = tid + 256 * i;
+                const int c = pc / VPC, piece = pc % VPC;
+                const bool ok = (VEXACT || pc < NCT * 32 * VPC) && c < CH && kt0 + piece * 8 < T;
+                if (VEXACT || pc < NCT * 32 * VPC) *reinterpret_cast<uint4*>(v_lds + c * VP + piece * 16) = ok ? vv[i] : make_uint4(0u, 0u, 0u, 0u);
+            }
+        } else {
+            for (int e = tid; e < NCT * 32 * KT; e += 256) {
+                const int c = e / KT, key = e % KT;
+                bf16_raw v = 0;
+                if (c < CH && kt0 + key < T) v = vbase[(size_t)c * T + kt0 + key];
+                *reinterpret_cast<bf16_raw*>(v_lds + c * VP + key * 2) = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < KIT; ++i) {
+            const int pc = tid + 256 * i;
+            const int key = pc / KPC, piece = pc % KPC;
+            if (KEXACT || pc < KT * KPC)
+                *reinterpret_cast<uint4*>(k_lds + KL::at(key, piece * 16)) = (kt0 + key < T) ? kv[i] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    if constexpr (PRE) load_kv(0);
+    for (int kt0 = 0; kt0 < T; kt0 += KT) {
         __syncthreads();
+        if constexpr (!PRE) load_kv(kt0);
+        store_kv(kt0);
+        __syncthreads();
+        if constexpr (PRE) {
+            if (kt0 + KT < T) load_kv(kt0 + KT);            // in flight under this tile's MFMAs
+        }
 
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
@@ -324,10 +369,34 @@ __global__ __launch_bounds__(256, CH <= 128 ? 2 : 1) void k_attn_dkv(const bf16_
     const float* const lbase = lse + ((size_t)b * heads + h) * T;
     const float* const ebase = delta + ((size_t)b * heads + h) * T;
 
-    for (int qt0 = 0; qt0 < T; qt0 += QT) {
-        __syncthreads();
-        {
-            uint4 vq[QIT], vd[QIT];
+    // Q / dO tiles.  PRE (CH <= 64): issue-early / write-late (T14), tile t + 1 fetched under the MFMAs of tile t; CH = 128 has no
+    // registers for that (232 of 256) and loads between the barriers.  Whole tiles use a scalar tile origin + per-thread 32-bit
+    // offsets computed once instead of clamps, selects and 64-bit multiplies per tile.
+    constexpr bool PRE = (CH <= 64);
+    uint4 vq[QIT], vd[QIT];
+    float nl_r = 0.0f, nd_r = 0.0f;
+    unsigned qoff[QIT], doff[QIT], qlds[QIT];
+#pragma unroll
+    for (int i = 0; i < QIT; ++i) {
+        const int pc = tid + 256 * i, q = pc / QPC, piece = pc % QPC;
+        qoff[i] = (unsigned)(((size_t)q * row2c + piece * 8) * 2);
+        doff[i] = (unsigned)(((size_t)q * C + piece * 8) * 2);
+        qlds[i] = (unsigned)QL::at(q, piece * 16);
+    }
+    auto load_q = [&](int qt0) {
+        if (QEXACT && qt0 + QT <= T) {                       // (uniform)
+            const char* const qb = reinterpret_cast<const char*>(qbase) + (size_t)qt0 * row2c * 2;
+            const char* const db = reinterpret_cast<const char*>(dbase) + (size_t)qt0 * C * 2;
+#pragma unroll
+            for (int i = 0; i < QIT; ++i) {
+                vq[i] = *reinterpret_cast<const uint4*>(qb + qoff[i]);
+                vd[i] = *reinterpret_cast<const uint4*>(db + doff[i]);
+            }
+            if (tid < QT) {
+                nl_r = -lbase[qt0 + tid];
+                if constexpr (DK) nd_r = -ebase[qt0 + tid] * scale;
+            }
+        } else {
 #pragma unroll
             for (int i = 0; i < QIT; ++i) {
                 const int pc = tid + 256 * i;
@@ -338,9 +407,23 @@ __global__ __launch_bounds__(256, CH <= 128 ? 2 : 1) void k_attn_dkv(const bf16_
             }
             if (tid < QT) {
                 const bool ok = qt0 + tid < T;
-                nlse_s[tid] = ok ? -lbase[qt0 + tid] : -INFINITY;          // exp2(-inf) = 0 masks the row
-                if constexpr (DK) ndel_s[tid] = ok ? -ebase[qt0 + tid] * scale : 0.0f;
+                nl_r = ok ? -lbase[qt0 + tid] : -INFINITY;          // exp2(-inf) = 0 masks the row
+                if constexpr (DK) nd_r = ok ? -ebase[qt0 + tid] * scale : 0.0f;
             }
+        }
+    };
+    auto store_q = [&](int qt0) {
+        if (tid < QT) {
+            nlse_s[tid] = nl_r;
+            if constexpr (DK) ndel_s[tid] = nd_r;
+        }
+        if (QEXACT && qt0 + QT <= T) {
+#pragma unroll
+            for (int i = 0; i < QIT; ++i) {
+                *reinterpret_cast<uint4*>(q_lds + qlds[i]) = vq[i];
+                *reinterpret_cast<uint4*>(d_lds + qlds[i]) = vd[i];
+            }
+        } else {
 #pragma unroll
             for (int i = 0; i < QIT; ++i) {
                 const int pc = tid + 256 * i;
@@ -352,7 +435,16 @@ __global__ __launch_bounds__(256, CH <= 128 ? 2 : 1) void k_attn_dkv(const bf16_
                 }
             }
         }
+    };
+    if constexpr (PRE) load_q(0);
+    for (int qt0 = 0; qt0 < T; qt0 += QT) {
         __syncthreads();
+        if constexpr (!PRE) load_q(qt0);
+        store_q(qt0);
+        __syncthreads();
+        if constexpr (PRE) {
+            if (qt0 + QT < T) load_q(qt0 + QT);             // in flight under this tile's MFMAs
+        }
 
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
@@ -490,10 +582,33 @@ __global__ __launch_bounds__(256, 2) void k_attn_dkv_fused(const bf16_raw* __res
     const float* const lbase = lse + ((size_t)b * heads + h) * T;
     const float* const ebase = delta + ((size_t)b * heads + h) * T;
 
-    for (int qt0 = 0; qt0 < T; qt0 += QT) {
-        __syncthreads();                  // (first pass: also publishes vb_lds)
-        {
-            uint4 vq[QIT], vd[QIT];
+    // Q / dO tiles: issue-early / write-late as in the forward kernel (cdna_hip_programming.md T14) - tile t + 1 is fetched into
+    // registers under the MFMAs of tile t and written to LDS between the two barriers; whole tiles (all but a ragged last one) use a
+    // scalar tile origin + per-thread 32-bit offsets computed once instead of clamps, selects and 64-bit multiplies per tile.
+    uint4 vq[QIT], vd[QIT];
+    float nl_r = 0.0f, nd_r = 0.0f;
+    unsigned qoff[QIT], doff[QIT], qlds[QIT];
+#pragma unroll
+    for (int i = 0; i < QIT; ++i) {
+        const int pc = tid + 256 * i, q = pc / QPC, piece = pc % QPC;
+        qoff[i] = (unsigned)(((size_t)q * row2c + piece * 8) * 2);
+        doff[i] = (unsigned)(((size_t)q * C + piece * 8) * 2);
+        qlds[i] = (unsigned)QL::at(q, piece * 16);
+    }
+    auto load_q = [&](int qt0) {
+        if (QEXACT && qt0 + QT <= T) {                       // (uniform)
+            const char* const qb = reinterpret_cast<const char*>(qbase) + (size_t)qt0 * row2c * 2;
+            const char* const db = reinterpret_cast<const char*>(dbase) + (size_t)qt0 * C * 2;
+#pragma unroll
+            for (int i = 0; i < QIT; ++i) {
+                vq[i] = *reinterpret_cast<const uint4*>(qb + qoff[i]);
+                vd[i] = *reinterpret_cast<const uint4*>(db + doff[i]);
+            }
+            if (tid < QT) {
+                nl_r = -lbase[qt0 + tid];
+                nd_r = -ebase[qt0 + tid] * scale;
+            }
+        } else {
 #pragma unroll
             for (int i = 0; i < QIT; ++i) {
                 const int pc = tid + 256 * i;
@@ -504,9 +619,23 @@ __global__ __launch_bounds__(256, 2) void k_attn_dkv_fused(const bf16_raw* __res
             }
             if (tid < QT) {
                 const bool ok = qt0 + tid < T;
-                nlse_s[tid] = ok ? -lbase[qt0 + tid] : -INFINITY;
-                ndel_s[tid] = ok ? -ebase[qt0 + tid] * scale : 0.0f;
+                nl_r = ok ? -lbase[qt0 + tid] : -INFINITY;
+                nd_r = ok ? -ebase[qt0 + tid] * scale : 0.0f;
             }
+        }
+    };
+    auto store_q = [&](int qt0) {
+        if (tid < QT) {
+            nlse_s[tid] = nl_r;
+            ndel_s[tid] = nd_r;
+        }
+        if (QEXACT && qt0 + QT <= T) {
+#pragma unroll
+            for (int i = 0; i < QIT; ++i) {
+                *reinterpret_cast<uint4*>(q_lds + qlds[i]) = vq[i];
+                *reinterpret_cast<uint4*>(d_lds + qlds[i]) = vd[i];
+            }
+        } else {
 #pragma unroll
             for (int i = 0; i < QIT; ++i) {
                 const int pc = tid + 256 * i;
@@ -518,7 +647,13 @@ __global__ __launch_bounds__(256, 2) void k_attn_dkv_fused(const bf16_raw* __res
                 }
             }
         }
+    };
+    load_q(0);
+    for (int qt0 = 0; qt0 < T; qt0 += QT) {
+        __syncthreads();                  // the previous tile is consumed (first pass: also publishes vb_lds)
+        store_q(qt0);
         __syncthreads();
+        if (qt0 + QT < T) load_q(qt0 + QT);      // in flight under this tile's MFMAs
 
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
