@@ -198,19 +198,21 @@ def roofline_of(plan, args):
     traffic = mfma_util = None
     traffic_note = "no PMC summary under profiles/ for this binary"
     import glob
-    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_traffic_{dom}.json")))[-1:]      # names carry the round: r03a > r02f
-    for tpath in newest:
+    # newest first (names carry the round: r03d > r03c > r02f); the first summary of THIS workload decides
+    workload = dict(dims=args.dims, grid=args.grid, mc=args.mc, batch=args.batch, dtype=args.dtype, labels=args.labels)
+    for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_traffic_{dom}.json")), reverse=True):
         with open(tpath) as f:
             tj = json.load(f)
+        if tj.get("workload") != workload:
+            continue
         if tj.get("build_id") != build:
             traffic_note = (f"{os.path.relpath(tpath, ROOT)} was measured on build {tj.get('build_id', '(unrecorded)')}, this is {build}: "
                             "not reported (re-run tests/gpu_pmc.sh)")
-        elif tj.get("workload") != dict(dims=args.dims, grid=args.grid, mc=args.mc, batch=args.batch, dtype=args.dtype, labels=args.labels):
-            traffic_note = f"{os.path.relpath(tpath, ROOT)} covers another workload"
         else:
             traffic, mfma_util = tj["hbm_bytes_per_launch"], tj.get("mfma_util")
             traffic_note = (f"{os.path.relpath(tpath, ROOT)} (build {build}; PMC FETCH_SIZE x2 + WRITE_SIZE, average per launch of the same "
                             f"{dom} launches)")
+        break
     alg_bytes = sum(p["bytes"] for p in sel)
     # Upsample + conv runs as 2-tap sub-pixel phases (12 of the 27 taps in 3-D): `achieved` / `frac` count the ALGORITHMIC FLOPs of
     # the reference's formulation (interpolate, then a 27-tap conv) as the contract asks; `executed_frac` counts the multiply-adds
