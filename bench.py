@@ -169,8 +169,8 @@ def dump_ops(path, prof):
 
 
 KIND_KERNEL = {
-    "conv3": "k_conv (3x3x3 implicit GEMM, LDS halo tile; the three Upsample convs as 2x2-tap sub-pixel phases)",
-    "conv1": "k_conv<.,1,1,1> (1x1x1 projections: skip / qkv / proj_out)",
+    "conv3": "k_conv (3x3x3 implicit GEMM, LDS halo tile; the three Upsample convs as 2x2-tap sub-pixel phases; ResBlock 1x1x1 skips folded into the out-conv launches)",
+    "conv1": "k_conv<.,1,1,1> (1x1x1 projections: qkv / proj_out / stem and head GEMM forms; skips where not folded)",
     "attention": "k_attn_bf16 (flash-style QK^T / PV on MFMA, fp32 online softmax)",
 }
 
@@ -225,6 +225,8 @@ def roofline_of(plan, args):
         "unit": "TFLOP/s", "frac": achieved / peak, "executed_frac": exe_tf / peak,
         "traffic": traffic, "traffic_source": traffic_note, "mfma_util": mfma_util,
         "build_id": build, "executed_flops_per_step": exe, "executed_TFLOPs": exe_tf,
+        # ResBlock skip convolutions (1x1x1) contracted inside their out-conv's launch (inference plans): part of the figures above
+        "folded_conv1_flops_per_step": sum(p.get("folded_conv1_flops", 0.0) for p in sel),
         "algorithmic_bytes_per_launch": alg_bytes / max(1, len(sel)), "algorithmic_flops_per_launch": fl / max(1, len(sel)),
         "launches_per_step": len(sel), "avg_launch_ms": ms / max(1, len(sel)),
         "algorithmic_bytes_per_step": alg_bytes, "algorithmic_flops_per_step": fl, "kernel_ms_per_step": ms,

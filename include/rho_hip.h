@@ -37,7 +37,7 @@ extern "C" {
 /* ABI version: bumped on ANY signature / struct-layout change (2: table_len in rho_q_sample(_coef), fmt in rho_gn_bwd_finalize,
  * rho_conv_desc grew; 3: round-3 additions).  A loader must compare rho_abi_version() with the header it was written against
  * before calling anything else (hip.py does; a build with all symbols but older signatures would be called with shifted arguments). */
-#define RHO_ABI_VERSION 4
+#define RHO_ABI_VERSION 5
 int rho_abi_version(void);
 /* static string: target arch + build flags */
 const char* rho_build_info(void);
@@ -229,6 +229,16 @@ typedef struct rho_conv_desc {
      * the preferred split wants (0: this launch is not split); a smaller workspace lowers the split count. */
     void* ws;
     int64_t ws_bytes;
+    /* --- a 1x1x1 convolution of ANOTHER input folded into this launch: out = conv(x) + sk_w * cat(sk_x1, sk_x2) + sk_bias, i.e. the
+     * ResBlock's `skip_connection(x) + out_layers(h)` (unet_v2.py:245-256,293) without the launch, the tensor and the residual
+     * read of the skip branch.  sk_w: prepared weights [1][coutp][sk_c1 + sk_c2] (rho_prep_conv_weight of the 1x1x1 parameter),
+     * sk_bias [coutp] float32 or NULL; sk_x1 / sk_x2 channels-last at the OUTPUT resolution.  bf16 3x3x3 stride-1 launches with a
+     * channels-last output only (RHO_E_ARG otherwise: the caller then launches the skip conv on its own and passes it as `res`). */
+    const void* sk_x1;
+    const void* sk_x2;
+    const void* sk_w;
+    const float* sk_bias;
+    int32_t sk_c1, sk_c2;
 } rho_conv_desc;
 
 /* n-D convolution, zero padding k/2, as an LDS-halo-staged implicit GEMM on MFMA.

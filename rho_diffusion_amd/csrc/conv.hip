@@ -81,6 +81,12 @@ struct ConvK {
     int ksplit;
     float* slab;
     long long slab_stride;      // floats per split
+    // Folded 1x1x1 skip convolution (rho_conv_desc.sk_*; FSK instantiations): contracted into the accumulators before the tap loop
+    const char* sk_x1;
+    const char* sk_x2;
+    const char* sk_w;
+    const float* sk_bias;
+    int sk_c1, sk_c2;
 };
 
 // floor(a / d) for 0 <= a < 2^20 with inv = 1.0f / d: (a + 0.5) * inv is at least 0.5 / d away from an integer, the
@@ -122,7 +128,7 @@ __device__ __forceinline__ int tile_position16(int m16, int i, int TW, int pair_
     return unit_position(2 * (m16 >> 1) + m16_hb(i), 2 * m16_k8(i) + (m16 & 1), TW, pair_lg);
 }
 
-template <typename T, int KD, int KH, int KW, int BM, int MAXP, int NW, bool M16 = false>
+template <typename T, int KD, int KH, int KW, int BM, int MAXP, int NW, bool M16 = false, bool FSK = false>
 // (second launch bound = waves per SIMD the register allocation must allow: 2 for the 8-wave variants and for the 4-wave 1x1x1
 //  variant, which without it took 241 VGPRs + 64 AGPRs = one workgroup per CU and left its HBM-bound layers at 3.3 TB/s)
 __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 10)) ? 2 : 1) void k_conv(const ConvK p) {
@@ -329,6 +335,94 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
             coef = cw_;
             __syncthreads();
         }
+    }
+    if constexpr (FSK) {
+        // ---- folded 1x1x1 skip convolution: acc += sk_w[co][:] . cat(sk_x1, sk_x2)[position][:] over the tile's 256 output positions,
+        // one "tap" of the M16 schedule per 32-channel chunk, BEFORE the tap loop touches LDS.  The activations are staged in the
+        // tile's own order (row r = position r of the tile: the odd 16-column tile of a pair is one row further, as in the halo)
+        // into two buffers over the bytes the halo tile and the weight ring use afterwards; chunk c + 1 is fetched while chunk c
+        // runs, one barrier per chunk.
+        static_assert(M16 && MT == 2 && KD == 3, "folded skip: the 64-couts-per-wave 16x16x32 layout of the 3-D kernels");
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+        constexpr int XR = 256 / RPP;                       // activation rows per thread
+        const int skc = p.sk_c1 + p.sk_c2, nsk = skc / CK;
+        char* const sa = smem;                               // [2][256 rows]
+        char* const sw = smem + 2 * 256 * PITCH;             // [2][BM rows]
+        int gp[XR];
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            const int r = (tid >> 2) + RPP * i;
+            const int od = od0 + (r >> (p.lgTW + p.lgTH)), oh = oh0 + ((r >> p.lgTW) & (p.TH - 1)), ow = ow0 + (r & (p.TW - 1));
+            const bool ok = od < p.Do && oh < p.Ho && ow < p.Wo;
+            gp[i] = ok ? ((n * p.Do + od) * p.Ho + oh) * p.Wo + ow : -1;
+        }
+        int cb[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            cb[j] = tile_position16(2 * (wpos * 2 + j), lane & 15, p.TW, p.pair_lg) * PITCH + 16 * (lane >> 4);
+        const unsigned skw_voff = (unsigned)(tid >> 2) * (unsigned)skc * (unsigned)sizeof(T) + (unsigned)piece * 16u;
+        const char* const skw0 = p.sk_w + (size_t)co0 * skc * sizeof(T);
+        uint4 xr[XR], wr0 = make_uint4(0u, 0u, 0u, 0u), wr1 = make_uint4(0u, 0u, 0u, 0u);
+        auto sk_load = [&](int c) {
+            const int ch = c * CK;
+            const char* src;
+            int cs, csrc;
+            if (ch < p.sk_c1) { src = p.sk_x1; cs = p.sk_c1; csrc = ch; } else { src = p.sk_x2; cs = p.sk_c2; csrc = ch - p.sk_c1; }
+#pragma unroll
+            for (int i = 0; i < XR; ++i) {
+                const int ps = gp[i] > 0 ? gp[i] : 0;
+                xr[i] = *reinterpret_cast<const uint4*>(src + ((size_t)ps * cs + csrc) * sizeof(T) + piece * 16);
+            }
+            const char* ws_ = skw0 + (size_t)c * 64;
+            if (w_active) wr0 = *reinterpret_cast<const uint4*>(ws_ + skw_voff);
+            if constexpr (WROWS == 2) wr1 = *reinterpret_cast<const uint4*>(ws_ + (size_t)RPP * skc * sizeof(T) + skw_voff);
+        };
+        auto sk_store = [&](int slot) {
+#pragma unroll
+            for (int i = 0; i < XR; ++i) {
+                const int r = (tid >> 2) + RPP * i;
+                *reinterpret_cast<uint4*>(sa + (slot * 256 + r) * PITCH + piece * 16) = gp[i] >= 0 ? xr[i] : make_uint4(0u, 0u, 0u, 0u);
+            }
+            char* const wd = sw + slot * BM * PITCH + w_dst0;
+            if (w_active) *reinterpret_cast<uint4*>(wd) = wr0;
+            if constexpr (WROWS == 2) *reinterpret_cast<uint4*>(wd + RPP * PITCH) = wr1;
+        };
+        auto sk_mm = [&](const u32x4_t (&fa)[2], const u32x4_t (&fb)[2], int tp, int jp) {
+            f32x16_t& c = acc[tp][jp];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int q = 4 * (2 * tt + jj);
+                    f32x4_t v = {c[q], c[q + 1], c[q + 2], c[q + 3]};
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[tt]), __builtin_bit_cast(bf16x8_t, fb[jj]), v, 0, 0, 0);
+                    c[q] = v[0]; c[q + 1] = v[1]; c[q + 2] = v[2]; c[q + 3] = v[3];
+                }
+        };
+        sk_load(0);
+        for (int c = 0; c < nsk; ++c) {
+            const int slot = c & 1;
+            sk_store(slot);                                  // (slot last read in iteration c - 2: every wave has passed the barrier of c - 1)
+            if (c + 1 < nsk) sk_load(c + 1);
+            __syncthreads();
+            u32x4_t fa01[2], fa23[2], fb0[2], fb1[2];
+            const char* const wA = sw + slot * BM * PITCH + a_off;
+            const char* const xB = sa + slot * 256 * PITCH;
+            fa01[0] = *reinterpret_cast<const u32x4_t*>(wA);
+            fa01[1] = *reinterpret_cast<const u32x4_t*>(wA + PITCH);
+            fb0[0] = *reinterpret_cast<const u32x4_t*>(xB + cb[0]);
+            fb0[1] = *reinterpret_cast<const u32x4_t*>(xB + cb[0] + PITCH);
+            fb1[0] = *reinterpret_cast<const u32x4_t*>(xB + cb[1]);
+            fb1[1] = *reinterpret_cast<const u32x4_t*>(xB + cb[1] + PITCH);
+            fa23[0] = *reinterpret_cast<const u32x4_t*>(wA + 32 * PITCH);
+            fa23[1] = *reinterpret_cast<const u32x4_t*>(wA + 33 * PITCH);
+            sk_mm(fa01, fb0, 0, 0);
+            sk_mm(fa01, fb1, 0, 1);
+            sk_mm(fa23, fb0, 1, 0);
+            sk_mm(fa23, fb1, 1, 1);
+        }
+        __syncthreads();                                     // the tap loop's prologue overwrites these LDS bytes
     }
     const char* wl = w_src0;
     if constexpr (NT != 1) {
@@ -881,6 +975,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                 for (int q4 = 0; q4 < PE / 4; ++q4) {
                     const float4 b4 = *reinterpret_cast<const float4*>(q.bias + co0 + piece * PE + q4 * 4);
                     bia[q4 * 4 + 0] = b4.x; bia[q4 * 4 + 1] = b4.y; bia[q4 * 4 + 2] = b4.z; bia[q4 * 4 + 3] = b4.w;
+                    if constexpr (FSK) {
+                        if (q.sk_bias != nullptr) {          // the folded skip convolution's own bias
+                            const float4 s4 = *reinterpret_cast<const float4*>(q.sk_bias + co0 + piece * PE + q4 * 4);
+                            bia[q4 * 4 + 0] += s4.x; bia[q4 * 4 + 1] += s4.y; bia[q4 * 4 + 2] += s4.z; bia[q4 * 4 + 3] += s4.w;
+                        }
+                    }
                     if constexpr (KD == 3) {
                         if (q.res_add != nullptr) {
                             const float4 e = *reinterpret_cast<const float4*>(q.res_add + (long long)n * q.res_add_stride + co0 + piece * PE + q4 * 4);
@@ -1170,14 +1270,14 @@ struct VariantOut {
 };
 thread_local VariantOut* g_variant = nullptr;
 
-template <typename T, int KD, int KH, int KW, int BM, int MAXP, int NW, bool M16 = false>
+template <typename T, int KD, int KH, int KW, int BM, int MAXP, int NW, bool M16 = false, bool FSK = false>
 int launch_one(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
     if (g_variant != nullptr) {
-        snprintf(g_variant->buf, (size_t)g_variant->cap, "k_conv<%s,%d,%d,%d,BM=%d,MAXP=%d,NW=%d,M16=%d>", sizeof(T) == 2 ? "bf16" : "f32",
-                 KD, KH, KW, BM, MAXP, NW, (int)M16);
+        snprintf(g_variant->buf, (size_t)g_variant->cap, "k_conv<%s,%d,%d,%d,BM=%d,MAXP=%d,NW=%d,M16=%d>%s", sizeof(T) == 2 ? "bf16" : "f32",
+                 KD, KH, KW, BM, MAXP, NW, (int)M16, FSK ? "+skip" : "");
         return 0;
     }
-    auto fn = k_conv<T, KD, KH, KW, BM, MAXP, NW, M16>;
+    auto fn = k_conv<T, KD, KH, KW, BM, MAXP, NW, M16, FSK>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -1196,10 +1296,17 @@ int launch_bm(const ConvK& k, int BM, int np, dim3 grid, size_t lds, bool m16, h
     if constexpr (sizeof(T) == 2 && KD * KH * KW > 1 && (KD * KH * KW) % 3 == 0) {
         // bf16, stride 1, no upsampling, regular halo: the 16x16x32 MFMA layout (holds a higher clock under load)
         if (m16 && np <= 640) {
+            if constexpr (KD == 3 && KH == 3 && KW == 3) {
+                if (k.sk_w != nullptr) {                   // (conv_impl only sets it for this geometry)
+                    if (BM == 128) return launch_one<T, KD, KH, KW, 128, 5, 8, true, true>(k, grid, lds, st);
+                    if (BM == 64) return launch_one<T, KD, KH, KW, 64, 10, 4, true, true>(k, grid, lds, st);
+                }
+            }
             if (BM == 128) return launch_one<T, KD, KH, KW, 128, 5, 8, true>(k, grid, lds, st);
             if (BM == 64) return launch_one<T, KD, KH, KW, 64, 10, 4, true>(k, grid, lds, st);
         }
     }
+    if (k.sk_w != nullptr) return RHO_E_ARG;               // a folded skip needs one of the two variants above
     if (BM == 128) {
         if (np <= 640) return launch_one<T, KD, KH, KW, 128, 5, 8>(k, grid, lds, st);
         if constexpr (!PHASE) return launch_one<T, KD, KH, KW, 128, 14, 8>(k, grid, lds, st);
@@ -1233,6 +1340,11 @@ int launch_taps(const rho_conv_desc& d, const ConvK& k, int BM, int np, dim3 gri
 }
 
 }  // namespace
+
+static bool m16_env_on() {
+    static const bool on = !(getenv("RHO_CONV_M16") && atoi(getenv("RHO_CONV_M16")) == 0);
+    return on;
+}
 
 static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles, int64_t* ws_want = nullptr) {
     if (!dp) return RHO_E_ARG;
@@ -1405,6 +1517,18 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
         k.gnb_c1 = d.gnb_c1; k.gnb_silu = d.gnb_silu;
     }
     size_t lds = (size_t)t.NP * PITCH + (size_t)WSLOTS * BM * PITCH;
+    k.sk_w = nullptr;
+    size_t lds_sk = 0;
+    if (d.sk_w) {
+        // folded 1x1x1 skip: the 16x16x32 3x3x3 variants only (bf16, stride 1, whole output channels-last, same-size input)
+        if (!d.sk_x1 || d.sk_c1 <= 0 || d.sk_c1 % CK || d.sk_c2 < 0 || d.sk_c2 % CK || ((d.sk_c2 > 0) != (d.sk_x2 != nullptr))) return RHO_E_ARG;
+        if (!(m16 && m16_env_on() && d.kd == 3 && d.kh == 3 && d.kw == 3 && t.NP <= 640 && (BM == 64 || BM == 128) && d.split == d.cout &&
+              !d.zs_h && !d.zs_w && !d.ph_h && !d.ph_w && !d.phd_h && !d.phd_w))
+            return RHO_E_ARG;
+        k.sk_x1 = (const char*)d.sk_x1; k.sk_x2 = (const char*)d.sk_x2; k.sk_w = (const char*)d.sk_w; k.sk_bias = d.sk_bias;
+        k.sk_c1 = d.sk_c1; k.sk_c2 = d.sk_c2;
+        lds_sk = (size_t)2 * 256 * PITCH + (size_t)2 * BM * PITCH;
+    }
     k.coef_off = 0;
     if (taps > 1 && d.kd == 3 && d.pre_a && lds + (size_t)2 * cin * sizeof(float) <= (BM == 128 ? lds_cap : lds_cap / 2)) {
         k.coef_off = (int)lds;                                    // after the halo tile and the weight ring
@@ -1412,11 +1536,13 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
     }
     if (taps == 1)        // 1x1x1: double-buffered activations + weights + the prologue coefficients of one sample
         lds = (size_t)2 * 256 * PITCH + (size_t)2 * BM * PITCH + (d.pre_a ? (size_t)2 * k.cin * sizeof(float) : 0);
+    if (k.coef_off > 0 && (size_t)k.coef_off < lds_sk) { lds -= (size_t)2 * cin * sizeof(float); k.coef_off = 0; }   // (the skip phase's buffers would overlap them)
+    if (lds < lds_sk) lds = lds_sk;
     if (d.stats) { const size_t lr = (size_t)(BM == 128 ? 512 : 256) * 16 * sizeof(float); if (lds < lr) lds = lr; }
     const size_t lds_epi = (size_t)256 * (BM * 4 + 16);       // epilogue transpose staging (fp32 rows, all 256 positions at once)
     if (d.split > 0 && lds < lds_epi) lds = lds_epi;
     hipStream_t st = as_stream(stream);
-    static const bool m16_env = !(getenv("RHO_CONV_M16") && atoi(getenv("RHO_CONV_M16")) == 0);
+    const bool m16_env = m16_env_on();
     const int rc = d.dtype == RHO_BF16 ? launch_taps<bf16_raw>(d, k, BM, t.NP, grid, lds, m16 && m16_env, st)
                                        : launch_taps<float>(d, k, BM, t.NP, grid, lds, false, st);
     if (rc != 0 || ksplit == 1 || g_variant != nullptr) return rc;

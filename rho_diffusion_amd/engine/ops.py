@@ -299,7 +299,7 @@ def make_conv_desc(x1: Tensor, x2: Optional[Tensor], w: Tensor, bias: Tensor, *,
                    pre_a: Optional[Tensor] = None, pre_b: Optional[Tensor] = None, pre_silu: bool = False,
                    res: Optional[Tensor] = None, res_add: Optional[Tensor] = None, res_add_stride: int = 0,
                    y2_cl: bool = False, res2: Optional[Tensor] = None, zs_hw=(0, 0), out_hw=(0, 0), phase_hw=(0, 0),
-                   phase_dgrad_hw=(0, 0)) -> ConvDesc:
+                   phase_dgrad_hw=(0, 0), skip: Optional[tuple] = None) -> ConvDesc:
     N, D, H, W, c1 = x1.shape
     d = ConvDesc()
     d.x1, d.x2 = ptr(x1), ptr(x2)
@@ -330,6 +330,14 @@ def make_conv_desc(x1: Tensor, x2: Optional[Tensor], w: Tensor, bias: Tensor, *,
         d.w_ = W // 2
     if w.shape[2] != d.c1 + d.c2:
         raise RhoHipError(f"conv: prepared weight has {w.shape[2]} input channels, inputs provide {d.c1 + d.c2}")
+    if skip is not None:
+        # (sx1, sx2, prepared 1x1x1 weights [1, coutp, c], bias): out += W_skip . cat(sx1, sx2) + b_skip inside this launch (rho_conv_desc.sk_*)
+        sx1, sx2, sw, sb = skip
+        d.sk_x1, d.sk_x2, d.sk_w, d.sk_bias = ptr(sx1), ptr(sx2), ptr(sw), ptr(sb)
+        d.sk_c1 = sx1.shape[-1]
+        d.sk_c2 = sx2.shape[-1] if sx2 is not None else 0
+        if sw.shape[0] != 1 or sw.shape[1] != w.shape[1] or sw.shape[2] != d.sk_c1 + d.sk_c2:
+            raise RhoHipError(f"conv: folded skip weights {tuple(sw.shape)} do not match coutp {w.shape[1]} / {d.sk_c1 + d.sk_c2} input channels")
     return d
 
 

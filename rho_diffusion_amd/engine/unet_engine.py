@@ -421,6 +421,8 @@ class _Plan:
         self.phase_upsample = os.environ.get("RHO_PHASE_UPSAMPLE", "1") != "0"
         self.phase_upsample_bwd = os.environ.get("RHO_PHASE_UPSAMPLE_BWD", "1") != "0"
         self.phase_min_wgs = int(os.environ.get("RHO_PHASE_MIN_WGS", "256"))
+        # inference plans of the bf16 engine: the ResBlock's 1x1x1 skip convolution inside its out-conv launch (A/B switch)
+        self.fold_skip = (not train) and eng.dtype == torch.bfloat16 and os.environ.get("RHO_FOLD_SKIP", "1") != "0"
         self.s2_split = os.environ.get("RHO_S2_SPLIT", "1") != "0"
         self.s2_split_bwd = os.environ.get("RHO_S2_SPLIT_BWD", "1") != "0"
         # backward: GroupNorm's reductions (sum dz, sum dz * x) in the epilogue of the dgrad launch that produces dz (A/B switch)
@@ -532,7 +534,7 @@ class _Plan:
             return dict(x1=x1, x2=x2, norm=norm, film_off=off, a=a, b=b, st=st, part=part, N=N, S=S, C=Cc, nblk=nblk)
 
         def conv(x1, x2, cw, *, stride_hw=(1, 1), up_hw=(0, 0), pre=None, pre_silu=False, res=None, res_add_off=None,
-                 split=None, y2_dtype=None, stem=False, want_stats=True, ckpt=False):
+                 split=None, y2_dtype=None, stem=False, want_stats=True, ckpt=False, fold_skip=None):
             cout = cw.cout
             split_ = cout if split is None else split
             N, Do, Ho, Wo = ops.conv_out_shape(x1.shape, cw.kernel, stride_hw, up_hw)
@@ -590,7 +592,8 @@ class _Plan:
             else:
                 d = ops.make_conv_desc(cx1, cx2, cw.w, cw.b, kernel=cw.kernel, cout=cout, split=split_, y=y, y2=y2,
                                        stride_hw=stride_hw, up_hw=up_hw, pre_a=cpre["a"] if cpre else None,
-                                       pre_b=cpre["b"] if cpre else None, pre_silu=pre_silu if cpre else False, res=res, res_add=None)
+                                       pre_b=cpre["b"] if cpre else None, pre_silu=pre_silu if cpre else False, res=res, res_add=None,
+                                       skip=fold_skip)
                 if res_add_off is not None:
                     d.res_add = self.film.data_ptr() + 4 * res_add_off
                     d.res_add_stride = self.film.shape[1]
@@ -685,7 +688,26 @@ class _Plan:
                 assert h2 is None
                 sk = h1
             else:
-                sk, _ = conv(h1, h2, eng._conv(blk.skip_connection))
+                skw, ocw = eng._conv(blk.skip_connection), eng._conv(blk.out_layers[3])
+                if self.fold_skip and skw.taps == 1 and ocw.taps == 27:
+                    # inference: skip_connection(x) + out_layers(h) (unet_v2.py:245-256,293) in ONE launch - the 1x1x1 skip is
+                    # contracted into the out-conv's accumulators before its tap loop (rho_conv_desc.sk_*): no launch, no `sk`
+                    # tensor written and read back as the residual.  Where the kernel has no such variant (rho_conv_variant says
+                    # so: narrow / wide cout tiles, large halos) the two launches stay.
+                    fs = (h1, h2, skw.w, skw.b)
+                    probe = ops.make_conv_desc(t1, None, ocw.w, ocw.b, kernel=ocw.kernel, cout=ocw.cout, split=ocw.cout,
+                                               y=t1, y2=None, skip=fs)
+                    if L.rho_conv_variant(C.byref(probe), C.create_string_buffer(128), 128) == 0:
+                        out, _ = conv(t1, None, ocw, pre=g2, pre_silu=True, ckpt=ck, fold_skip=fs)
+                        # the launch's work = the 27-tap conv + the folded 1x1x1 (both algorithmic FLOPs of the reference's
+                        # formulation); the 1x1x1 share is also reported on its own (bench: roofline.folded_conv1_flops_per_step)
+                        fl = 2.0 * (t1.numel() // t1.shape[-1]) * ocw.cout * skw.cin
+                        self.info[-1]["flops"] += fl
+                        self.info[-1]["executed_flops"] += fl
+                        self.info[-1]["folded_conv1_flops"] = fl
+                        self.info[-1]["bytes"] += float(esz) * (t1.numel() // t1.shape[-1]) * skw.cin
+                        return out
+                sk, _ = conv(h1, h2, skw)
             out, _ = conv(t1, None, eng._conv(blk.out_layers[3]), pre=g2, pre_silu=True, res=sk, ckpt=ck)
             return out
 

@@ -332,6 +332,88 @@ def _plan_variants(ops, kw, xshape, dtype, has_y, train):
     return out
 
 
+# ----------------------------------------------------------------------------- ResBlock skip folded into the out-conv launch
+FOLD_CASES = [
+    # name, cout, skip c1, skip c2, spatial (N = 1): out = conv3x3x3(silu(a h + b)) + conv1x1x1(cat(x1, x2)) (unet_v2.py:245-256,293)
+    ("c3_fold_192_64", 64, 128, 64, (64, 64, 64)),          # 64-cout tiles, 4 waves
+    ("c3_fold_384_128", 128, 256, 128, (64, 32, 32)),       # 128-cout tiles, 8 waves
+    ("c5_fold_96_64", 64, 64, 32, (128, 64, 64)),
+    ("fold_ragged", 64, 32, 0, (5, 9, 11)),                 # partial tiles on every axis, one source
+]
+
+
+def _run_fold_skip(ops, case, check=True):
+    name, cout, c1, c2, spatial = case
+    N, dtype = 1, BF16
+    if not check and name != "fold_ragged":
+        spatial = (16, 16, 16)                               # (the variant depends on the tile and the cout, not on the extent)
+    h = rnd(det_normal((N, cout, *spatial), name + "h"), dtype)
+    x = rnd(det_normal((N, c1 + c2, *spatial), name + "x"), dtype)
+    w3 = rnd(det_normal((cout, cout, 3, 3, 3), name + "w3") / math.sqrt(cout * 27), dtype)
+    w1 = rnd(det_normal((cout, c1 + c2, 1, 1, 1), name + "w1") / math.sqrt(c1 + c2), dtype)
+    b3, b1 = det_normal((cout,), name + "b3") * 0.1, det_normal((cout,), name + "b1") * 0.1
+    pre = (1 + 0.3 * det_normal((N, cout), name + "a"), 0.2 * det_normal((N, cout), name + "pb"))
+    hcl = to_cl(h, dtype)
+    x1cl = to_cl(x[:, :c1], dtype)
+    x2cl = to_cl(x[:, c1:], dtype) if c2 else None
+    wp3, wp1 = ops.prep_conv_weight(w3.to(DEV), dtype), ops.prep_conv_weight(w1.to(DEV), dtype)
+    bp3, bp1 = b3.to(DEV), b1.to(DEV)
+    pa, pb = pre[0].to(DEV), pre[1].to(DEV)
+    y = torch.full((N, *spatial, cout), float("nan"), dtype=dtype, device=DEV)
+    d = ops.make_conv_desc(hcl, None, wp3, bp3, kernel=(3, 3, 3), cout=cout, split=cout, y=y, y2=None, pre_a=pa, pre_b=pb, pre_silu=True,
+                           skip=(x1cl, x2cl, wp1, bp1))
+    variants = {ops.conv_variant(d)}
+    assert all(v.endswith("+skip") for v in variants), variants
+    if check:
+        tiles = ops.conv_stats_tiles(d)
+        sbuf = torch.zeros(N * tiles * 2 * cout, device=DEV)
+        d.stats = sbuf.data_ptr()
+        ops.conv_launch(d)
+        torch.cuda.synchronize()
+        shp = (N, cout, 1, 1, 1)
+        ha = rnd(F.silu(pre[0].reshape(shp) * h + pre[1].reshape(shp)), dtype)
+        ref = R.conv_nd(3, ha, w3, b3, stride=1, padding=1) + R.conv_nd(3, x, w1, b1, stride=1, padding=0)
+        got = from_cl(y, 3)
+        assert torch.isfinite(got).all()
+        assert rel_l2(got, ref) < 6e-3, f"{name}: {rel_l2(got, ref):.3e}"
+        # the fused GroupNorm statistics are those of the stored sum
+        st = sbuf.view(N, tiles, 2, cout).sum(1)
+        yy = y.float().reshape(N, -1, cout)
+        assert rel_l2(st[:, 0], yy.sum(1)) < 1e-3 and rel_l2(st[:, 1], (yy * yy).sum(1)) < 1e-3
+        # and the two-launch form it replaces (skip conv, then the out-conv with the residual) agrees to bf16 rounding of `sk`
+        sk, _ = ops.conv(x1cl, x2cl, wp1, bp1, kernel=(1, 1, 1), cout=cout)
+        y2l, _ = ops.conv(hcl, None, wp3, bp3, kernel=(3, 3, 3), cout=cout, pre_a=pa, pre_b=pb, pre_silu=True, res=sk)
+        assert rel_l2(got, from_cl(y2l, 3)) < 6e-3
+    return variants
+
+
+@pytest.mark.parametrize("case", FOLD_CASES, ids=[c[0] for c in FOLD_CASES])
+def test_resblock_skip_folded_into_the_out_conv(ops, case):
+    _run_fold_skip(ops, case)
+
+
+def test_folded_skip_is_refused_where_no_variant_exists(ops):
+    """fp32, 2-D, narrow (32-cout) and strided launches have no folded variant: RHO_E_ARG, the caller keeps two launches."""
+    from rho_diffusion_amd import hip
+
+    def rc(dtype, kernel, cout, spatial4, stride_hw=(1, 1)):
+        x = torch.zeros(1, *spatial4[:3], cout, dtype=dtype, device=DEV)
+        nd = 3 if kernel[0] > 1 else 2
+        wp3 = ops.prep_conv_weight(torch.zeros((cout, cout) + kernel[3 - nd:], device=DEV), dtype)
+        wp1 = ops.prep_conv_weight(torch.zeros((cout, 64) + (1,) * nd, device=DEV), dtype)
+        sx = torch.zeros(1, *spatial4[:3], 64, dtype=dtype, device=DEV)
+        d = ops.make_conv_desc(x, None, wp3, torch.zeros(wp3.shape[1], device=DEV), kernel=kernel, cout=cout, split=cout, y=x, y2=None,
+                               stride_hw=stride_hw, skip=(sx, None, wp1, None))
+        import ctypes as C
+        return hip.lib().rho_conv_variant(C.byref(d), C.create_string_buffer(128), 128)
+
+    assert rc(BF16, (3, 3, 3), 64, (8, 8, 8)) == 0
+    assert rc(F32, (3, 3, 3), 64, (8, 8, 8)) != 0
+    assert rc(BF16, (1, 3, 3), 64, (1, 16, 16)) != 0
+    assert rc(BF16, (3, 3, 3), 32, (8, 8, 8)) != 0
+    assert rc(BF16, (3, 3, 3), 64, (8, 8, 8), stride_hw=(2, 2)) != 0
+
+
 def test_parity_cases_cover_every_variant_the_bench_plans_launch(ops):
     """c3 (3-D 64^3 mc 64 bf16), c5 (3-D 128^3 mc 32 conditioned bf16), c2 (2-D 128^2 mc 64 fp32): inference and training plans.
     (The plan's variants depend on the per-sample geometry, not on the batch: batch 1 / 4 as in the parity cases.)"""
@@ -339,6 +421,8 @@ def test_parity_cases_cover_every_variant_the_bench_plans_launch(ops):
     covered = set()
     for case in LAYER_CASES:
         covered |= _SEEN.get(case[0]) or _run_layer(ops, case, check=False)
+    for case in FOLD_CASES:
+        covered |= _run_fold_skip(ops, case, check=False)
     plans = {
         "c3": (dict(base, model_channels=64, dims=3, data_shape=[64, 64, 64]), (1, 1, 64, 64, 64), BF16, False),
         "c5": (dict(base, model_channels=32, dims=3, data_shape=[128, 128, 128], num_classes=25), (1, 1, 128, 128, 128), BF16, True),
