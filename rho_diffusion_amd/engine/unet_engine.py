@@ -421,8 +421,10 @@ class _Plan:
         self.phase_upsample = os.environ.get("RHO_PHASE_UPSAMPLE", "1") != "0"
         self.phase_upsample_bwd = os.environ.get("RHO_PHASE_UPSAMPLE_BWD", "1") != "0"
         self.phase_min_wgs = int(os.environ.get("RHO_PHASE_MIN_WGS", "256"))
-        # inference plans of the bf16 engine: the ResBlock's 1x1x1 skip convolution inside its out-conv launch (A/B switch)
-        self.fold_skip = (not train) and eng.dtype == torch.bfloat16 and os.environ.get("RHO_FOLD_SKIP", "1") != "0"
+        # bf16 engine: the ResBlock's 1x1x1 skip convolution inside its out-conv's forward launch (A/B switches)
+        # (training plans: the forward launch only - backward keeps the skip branch's own data / weight-gradient launches)
+        self.fold_skip = (eng.dtype == torch.bfloat16 and os.environ.get("RHO_FOLD_SKIP", "1") != "0"
+                          and (not train or os.environ.get("RHO_FOLD_SKIP_TRAIN", "1") != "0"))
         self.s2_split = os.environ.get("RHO_S2_SPLIT", "1") != "0"
         self.s2_split_bwd = os.environ.get("RHO_S2_SPLIT_BWD", "1") != "0"
         # backward: GroupNorm's reductions (sum dz, sum dz * x) in the epilogue of the dgrad launch that produces dz (A/B switch)
@@ -534,7 +536,7 @@ class _Plan:
             return dict(x1=x1, x2=x2, norm=norm, film_off=off, a=a, b=b, st=st, part=part, N=N, S=S, C=Cc, nblk=nblk)
 
         def conv(x1, x2, cw, *, stride_hw=(1, 1), up_hw=(0, 0), pre=None, pre_silu=False, res=None, res_add_off=None,
-                 split=None, y2_dtype=None, stem=False, want_stats=True, ckpt=False, fold_skip=None):
+                 split=None, y2_dtype=None, stem=False, want_stats=True, ckpt=False, fold_skip=None, node_res=None):
             cout = cw.cout
             split_ = cout if split is None else split
             N, Do, Ho, Wo = ops.conv_out_shape(x1.shape, cw.kernel, stride_hw, up_hw)
@@ -622,8 +624,10 @@ class _Plan:
                     executed_flops=2.0 * npos_out * cout * cw.cin * taps_run / (1 if s2 else len(descs)),
                     bytes=float(esz) * (npos_in * cw.cin + npos_out * cout * (2 if res is not None else 1) / len(descs)
                                         + taps_run * cout * cw.cin)))
+            # (node_res: the backward's view of a folded skip - the gradient of this output also belongs to the skip branch's node)
             self.nodes.append(dict(k="conv", cw=cw, x1=x1, x2=x2, y=y, y2=y2, stride_hw=stride_hw, up_hw=up_hw, pre=pre,
-                                   pre_silu=pre_silu, res=res, res_add_off=res_add_off, stem=stem, out_dims=(N, Do, Ho, Wo),
+                                   pre_silu=pre_silu, res=res if node_res is None else node_res, res_add_off=res_add_off, stem=stem,
+                                   out_dims=(N, Do, Ho, Wo),
                                    xact=xact if keep_act else None, phased=phased, s2=s2))
             return y, y2
 
@@ -690,7 +694,7 @@ class _Plan:
             else:
                 skw, ocw = eng._conv(blk.skip_connection), eng._conv(blk.out_layers[3])
                 if self.fold_skip and skw.taps == 1 and ocw.taps == 27:
-                    # inference: skip_connection(x) + out_layers(h) (unet_v2.py:245-256,293) in ONE launch - the 1x1x1 skip is
+                    # skip_connection(x) + out_layers(h) (unet_v2.py:245-256,293) in ONE forward launch - the 1x1x1 skip is
                     # contracted into the out-conv's accumulators before its tap loop (rho_conv_desc.sk_*): no launch, no `sk`
                     # tensor written and read back as the residual.  Where the kernel has no such variant (rho_conv_variant says
                     # so: narrow / wide cout tiles, large halos) the two launches stay.
@@ -698,7 +702,16 @@ class _Plan:
                     probe = ops.make_conv_desc(t1, None, ocw.w, ocw.b, kernel=ocw.kernel, cout=ocw.cout, split=ocw.cout,
                                                y=t1, y2=None, skip=fs)
                     if L.rho_conv_variant(C.byref(probe), C.create_string_buffer(128), 128) == 0:
-                        out, _ = conv(t1, None, ocw, pre=g2, pre_silu=True, ckpt=ck, fold_skip=fs)
+                        skd = None
+                        if self.train:
+                            # backward is the unfused graph: a node for the skip branch whose "output" is a key-only tensor; the
+                            # out-conv's node names it as its residual, so its dY is aliased to the skip node exactly as before
+                            skd = buf(8, dtype=torch.uint8)
+                            N_, D_, H_, W_ = t1.shape[:4]
+                            self.nodes.append(dict(k="conv", cw=skw, x1=h1, x2=h2, y=skd, y2=None, stride_hw=(1, 1), up_hw=(0, 0), pre=None,
+                                                   pre_silu=False, res=None, res_add_off=None, stem=False, out_dims=(N_, D_, H_, W_),
+                                                   xact=None, phased=False, s2=False))
+                        out, _ = conv(t1, None, ocw, pre=g2, pre_silu=True, ckpt=ck, fold_skip=fs, node_res=skd)
                         # the launch's work = the 27-tap conv + the folded 1x1x1 (both algorithmic FLOPs of the reference's
                         # formulation); the 1x1x1 share is also reported on its own (bench: roofline.folded_conv1_flops_per_step)
                         fl = 2.0 * (t1.numel() // t1.shape[-1]) * ocw.cout * skw.cin
