@@ -2,7 +2,7 @@
 files kept under profiles/:  <tag>_pmc_traffic_conv3.json (HBM bytes per launch of the 3x3x3 k_conv variants: FETCH_SIZE in
 KiB doubled per MI355X_MICROARCH.md's gfx950 correction + WRITE_SIZE in KiB) and <tag>_pmc_sq_counters_summary.json.
 usage: python tools/pmc_summary.py <tag> [steps_profiled]"""
-import collections, csv, glob, json, os, sys
+import collections, csv, glob, json, os, re, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
@@ -83,7 +83,9 @@ for k, v in sq.items():
 DUR = durations()
 for k, v in sq.items():
     if v.get("SQ_INSTS_MFMA") and DUR.get(k):
-        is_m16 = k.rstrip(")").rstrip().endswith("true>(ConvK") or ", true>" in k
+        m_ = re.search(r"k_conv<([^>]*)>", k)                 # template arguments: T, KD, KH, KW, BM, MAXP, NW, M16[, FSK]
+        a_ = [x.strip() for x in m_.group(1).split(",")] if m_ else []
+        is_m16 = len(a_) >= 8 and a_[7] == "true"
         cyc = 64.0 if "<float" in k else (16.0 if (is_m16 and "k_conv" in k) else 32.0)
         v["duration_s_trace_pass"] = DUR[k]
         v["mfma_cycles_per_inst_assumed"] = cyc
@@ -95,13 +97,16 @@ if PMC_DIR != "pmc":
 
 # the launches bench.py files under kind "conv3": the 27-tap kernels and the 12-tap sub-pixel phases of the Upsample convs
 # (... and the 1- / 2-tap parity launches of the stride-2 Downsample convs)
-conv3 = [k for k in sq if "k_conv<" in k and any(t in k for t in ("3, 3, 3", "3, 2, 2", "3, 1, 1", "3, 1, 2", "3, 2, 1"))]
+# (3-D workloads: kernel depth 3; 2-D workloads - c1 / c2 - run the same kinds on the 1 x k x k instantiations)
+dims = int((meta.get("workload") or {}).get("dims", 3))
+TAPS3 = ("3, 3, 3", "3, 2, 2", "3, 1, 1", "3, 1, 2", "3, 2, 1") if dims == 3 else ("1, 3, 3", "1, 2, 2", "1, 1, 2", "1, 2, 1", "1, 1, 3")
+conv3 = [k for k in sq if "k_conv<" in k and any(("short, " + t) in k or ("float, " + t) in k for t in TAPS3)]
 fetch = sum(sq[k].get("FETCH_SIZE", 0.0) for k in conv3) * 1024.0 * 2.0
 write = sum(sq[k].get("WRITE_SIZE", 0.0) for k in conv3) * 1024.0
 launches = sum(sq[k].get("_calls_fetch", 0) for k in conv3)
 mf = sum(sq[k].get("SQ_INSTS_MFMA", 0.0) * sq[k].get("mfma_cycles_per_inst_assumed", 32.0) for k in conv3)
 dsum = sum(DUR.get(k, 0.0) for k in conv3)
-tj = {"kernel": "k_conv<bf16,3,{3|2|1},{3|2|1},*> (all variants of the launches bench.py files under kind conv3)", "build_id": meta.get("build_id"), "workload": meta.get("workload"),
+tj = {"kernel": ("k_conv<bf16,3,{3|2|1},{3|2|1},*>" if dims == 3 else "k_conv<f32|bf16,1,{3|2|1},{3|2|1},*>") + " (all variants of the launches bench.py files under kind conv3)", "build_id": meta.get("build_id"), "workload": meta.get("workload"),
       "mfma_util": (mf / (1024.0 * dsum * 2.4e9)) if dsum > 0 else None,
       "effective_clock_GHz": ({k[:60]: round(CLK[k], 3) for k in conv3 if k in CLK} or None),
       "mfma_util_note": "sum over the conv3 variants of SQ_INSTS_MFMA x SIMD cycles per instruction / (1024 SIMDs x summed kernel time "
