@@ -37,7 +37,7 @@ extern "C" {
 /* ABI version: bumped on ANY signature / struct-layout change (2: table_len in rho_q_sample(_coef), fmt in rho_gn_bwd_finalize,
  * rho_conv_desc grew; 3: round-3 additions).  A loader must compare rho_abi_version() with the header it was written against
  * before calling anything else (hip.py does; a build with all symbols but older signatures would be called with shifted arguments). */
-#define RHO_ABI_VERSION 5
+#define RHO_ABI_VERSION 6
 int rho_abi_version(void);
 /* static string: target arch + build flags */
 const char* rho_build_info(void);
@@ -271,6 +271,23 @@ int rho_prep_conv_weight_sel(const float* w, void* out, int dtype, int64_t cout,
  * statistics are not available for this geometry (channel-major outputs, tiles that straddle samples: 1-D / 2-D
  * kernels, 1x1x1 with positions-per-sample not a multiple of 256); callers then fall back to rho_gn_partial. */
 int64_t rho_conv_stats_tiles(const rho_conv_desc* desc);
+
+/* The 1-channel ends of the 3-D UNet as single launches (bf16 inference plans; contraction over the 27 taps / taps as output rows,
+ * intermediates in LDS - see csrc/ends.hip).
+ *   rho_stem_conv3d: y[n, d, h, w, co] = bias[co] + sum_tap W[co][tap] x[n, 0, (d, h, w) + off(tap)]   (zero padding 1), the stem
+ *     `conv_nd(3, 1, mc, 3, padding=1)` (unet_v2.py:535).  x float32 [N, 1, D, H, W]; w = the prepared 1x1x1 weights of the im2col form
+ *     [coutp][32] bf16 (rho_prep_conv_weight of the parameter reshaped [cout, 27, 1, 1, 1]); y bf16 channels-last; cout 32 or 64.
+ *     stats: optional fused GroupNorm statistics of the stored output, float32 [N][rho_stem_conv3d_tiles(d, h, w)][2][cout]
+ *     (the layout of rho_conv_desc.stats, read by rho_gn_finalize2).
+ *   rho_head_conv3d: out[n, 0, d, h, w] = bias + sum_tap sum_c W[tap][c] act(a[n, c] x[(d, h, w) + off(tap)][c] + b[n, c]), the head
+ *     `GroupNorm32 -> SiLU -> conv_nd(3, mc, 1, 3, padding=1)` (unet_v2.py:679-683).  x bf16 channels-last [N, D, H, W, C], C in
+ *     {32, 64, 96, 128}; pre_a / pre_b [N, C] float32 (NULL: raw input), pre_silu; w = prepared [32][C] bf16 (rows = taps, 27 used);
+ *     out float32 [N, 1, D, H, W] (the reference layout). */
+int64_t rho_stem_conv3d_tiles(int64_t d, int64_t h, int64_t w);
+int rho_stem_conv3d(const float* x, const void* w, const float* bias, void* y, float* stats, int64_t n, int64_t d, int64_t h, int64_t w_,
+                    int64_t cout, void* stream);
+int rho_head_conv3d(const void* x, const float* pre_a, const float* pre_b, int pre_silu, const void* w, const float* bias, float* out,
+                    int64_t n, int64_t d, int64_t h, int64_t w_, int64_t c, void* stream);
 
 /* Workspace the k-split of `desc` wants (rho_conv_desc.ws), in bytes; 0 when the launch would not be split (3-D and 1x1x1 kernels,
  * phased / channel-major outputs, grids that already fill the chip).  Depends on geometry only: one allocation of the maximum over

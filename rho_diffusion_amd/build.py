@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "librho_hip.so")
 SOURCES = ["elementwise.hip", "groupnorm.hip", "conv.hip", "wgrad.hip", "attention.hip", "attention_bwd.hip", "select.hip", "embedding.hip",
-           "sph_harm.hip", "unet_v1.hip"]
+           "sph_harm.hip", "unet_v1.hip", "ends.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-I", INCLUDE, "-I", CSRC]
 

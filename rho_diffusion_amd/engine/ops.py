@@ -354,6 +354,27 @@ def conv_stats_tiles(desc: ConvDesc) -> int:
     return int(hip.lib().rho_conv_stats_tiles(C.byref(desc)))
 
 
+def stem_conv3d_tiles(d: int, h: int, w: int) -> int:
+    return int(hip.lib().rho_stem_conv3d_tiles(d, h, w))
+
+
+def stem_conv3d(x: Tensor, w: Tensor, bias: Tensor, y: Tensor, stats: Optional[Tensor] = None) -> None:
+    """rho_stem_conv3d: x float32 [N, 1, D, H, W] -> y bf16 channels-last [N, D, H, W, cout]; w = prepared im2col-form weights
+    [1, coutp, 32]; stats (optional) float32 [N, stem_conv3d_tiles(D, H, W), 2, cout]."""
+    hip.require_gpu(x, "x")
+    N, _, D, H, W = x.shape
+    check(hip.lib().rho_stem_conv3d(ptr(x), ptr(w), ptr(bias), ptr(y), ptr(stats), N, D, H, W, y.shape[-1], stream()), "rho_stem_conv3d")
+
+
+def head_conv3d(x: Tensor, pre_a: Optional[Tensor], pre_b: Optional[Tensor], pre_silu: bool, w: Tensor, bias: Optional[Tensor],
+                out: Tensor) -> None:
+    """rho_head_conv3d: x bf16 channels-last [N, D, H, W, C] -> out float32 [N, 1, D, H, W]; w = prepared taps-as-rows weights [1, 32, C]."""
+    hip.require_gpu(x, "x")
+    N, D, H, W, Cc = x.shape
+    check(hip.lib().rho_head_conv3d(ptr(x), ptr(pre_a), ptr(pre_b), int(pre_silu), ptr(w), ptr(bias), ptr(out), N, D, H, W, Cc, stream()),
+          "rho_head_conv3d")
+
+
 def conv_workspace_bytes(desc: ConvDesc) -> int:
     """Bytes of workspace the k-split of ``desc`` wants (rho_conv_desc.ws); 0: the launch is not split."""
     return int(hip.lib().rho_conv_workspace_bytes(C.byref(desc)))

@@ -756,6 +756,8 @@ class _Plan:
                     else:
                         up = (1, 1) if dims >= 2 else (0, 1)
                         h1, _ = conv(h1, None, eng._conv(layer.conv), up_hw=up)
+                elif stem_direct is not None:  # the stem conv as one launch on the fp32 input (rho_stem_conv3d)
+                    h1 = stem_direct()
                 else:  # the stem conv
                     h1, _ = conv(h1, None, stem, stem=True)
             return h1
@@ -766,7 +768,25 @@ class _Plan:
         gemm_ends = (not train) and dt == torch.bfloat16 and os.environ.get("RHO_GEMM_ENDS", "1") != "0"
         stem = eng._conv(m.input_blocks[0][0])
         self.x_in = buf(*xshape, dtype=torch.float32)
-        if gemm_ends and stem.taps > 1 and stem.cin * stem.taps <= 32:
+        # 3-D, one input / output channel: each end is ONE launch with its intermediate in LDS (csrc/ends.hip; A/B switch) instead
+        # of the GEMM form's two (im2col + GEMM, GEMM + tap gather)
+        direct_ends = gemm_ends and dims == 3 and os.environ.get("RHO_DIRECT_ENDS", "1") != "0"
+        stem_direct = None
+        if direct_ends and xshape[1] == 1 and tuple(stem.kernel) == (3, 3, 3) and stem.cout in (32, 64):
+            sg = eng._conv_as_gemm(m.input_blocks[0][0], _StemAsGemm)
+
+            def stem_direct():
+                y = buf(B, D, H, W, sg.cout)
+                tiles = ops.stem_conv3d_tiles(D, H, W)
+                sbuf = buf(B * tiles * 2 * sg.cout, dtype=torch.float32)
+                a = (ptr(self.x_in), ptr(sg.w), ptr(sg.b), ptr(y), ptr(sbuf), B, D, H, W, sg.cout)
+                self.ops.append(lambda s_, a=a: L.rho_stem_conv3d(*a, s_))
+                self.tstats[y.data_ptr()] = (sbuf, tiles)
+                npos = B * D * H * W
+                self.info.append(dict(kind="stem", flops=2.0 * npos * sg.cout * 27, bytes=4.0 * npos + float(esz) * npos * sg.cout))
+                return y
+            self.x_cl = self.x_in
+        elif gemm_ends and stem.taps > 1 and stem.cin * stem.taps <= 32:
             stem = eng._conv_as_gemm(m.input_blocks[0][0], _StemAsGemm)
             self.x_cl = buf(B, D, H, W, stem.cinp)
             pk = (ptr(self.x_in), ptr(self.x_cl), dtc, B, xshape[1], D, H, W) + stem.kernel3 + (stem.cinp,)
@@ -775,7 +795,8 @@ class _Plan:
             self.x_cl = buf(B, D, H, W, stem.cinp)
             pk = (ptr(self.x_in), ptr(self.x_cl), dtc, B, xshape[1], D * H * W, stem.cinp)
             self.ops.append(lambda s, a=pk: L.rho_pack_input(*a, s))
-        self.info.append(dict(kind="pack", flops=0.0, bytes=4.0 * B * xshape[1] * D * H * W + 2.0 * B * D * H * W * stem.cinp))
+        if stem_direct is None:
+            self.info.append(dict(kind="pack", flops=0.0, bytes=4.0 * B * xshape[1] * D * H * W + 2.0 * B * D * H * W * stem.cinp))
 
         hs = []
         h = self.x_cl
@@ -787,7 +808,15 @@ class _Plan:
             h = run_block(blk, h, hs.pop())
         g = gn(h, None, m.out[0])
         head = eng._conv(m.out[2])
-        if gemm_ends and head.taps > 1 and head.cout == 1:
+        if direct_ends and tuple(head.kernel) == (3, 3, 3) and head.cout == 1 and h.shape[-1] in (32, 64, 96, 128):
+            hg = eng._conv_as_gemm(m.out[2], _HeadAsGemm)
+            y2 = buf(B, 1, D * H * W, dtype=torch.float32)
+            ga = (ptr(h), ptr(g["a"]), ptr(g["b"]), 1, ptr(hg.w), ptr(m.out[2].bias), ptr(y2), B, D, H, W, h.shape[-1])
+            self.ops.append(lambda s, a=ga: L.rho_head_conv3d(*a, s))
+            self.keep.append(g)
+            npos = B * D * H * W
+            self.info.append(dict(kind="head", flops=2.0 * npos * h.shape[-1] * 27, bytes=float(esz) * npos * h.shape[-1] + 4.0 * npos))
+        elif gemm_ends and head.taps > 1 and head.cout == 1:
             hg = eng._conv_as_gemm(m.out[2], _HeadAsGemm)
             tt, _ = conv(h, None, hg, pre=g, pre_silu=True, want_stats=False)          # [B, D, H, W, 32]: one column per tap
             y2 = buf(B, 1, D * H * W, dtype=torch.float32)

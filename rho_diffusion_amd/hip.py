@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("RHO_HIP_LIB") or os.path.join(_HERE, "librho_hip.so")
 
 RHO_F32 = 0
 RHO_BF16 = 1
-ABI_VERSION = 5      # == RHO_ABI_VERSION of include/rho_hip.h (tests/test_cabi.py keeps the two equal)
+ABI_VERSION = 6      # == RHO_ABI_VERSION of include/rho_hip.h (tests/test_cabi.py keeps the two equal)
 
 c_void_p, c_int, c_int32, c_int64, c_uint64, c_float, c_double = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
 
@@ -72,6 +72,10 @@ SIGNATURES = {
     "rho_conv_nd_fwd": (c_int, [C.POINTER(ConvDesc), c_void_p]),
     "rho_conv_stats_tiles": (c_int64, [C.POINTER(ConvDesc)]),
     "rho_conv_workspace_bytes": (c_int64, [C.POINTER(ConvDesc)]),
+    "rho_stem_conv3d_tiles": (c_int64, [c_int64, c_int64, c_int64]),
+    "rho_stem_conv3d": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p]),
+    "rho_head_conv3d": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                c_int64, c_void_p]),
     "rho_conv_variant": (c_int, [C.POINTER(ConvDesc), C.c_char_p, c_int]),
     "rho_conv_wgrad_variant": (c_int, [C.POINTER(ConvDesc), c_int64, C.c_char_p, c_int]),
     "rho_gn_finalize2": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p,
