@@ -3,6 +3,8 @@ training_step, graph-captured sampling); the stand-alone MultiEmbeddings trains 
 (3-D 128^3 mc 32 conditioned, bf16) and c2 (2-D 128^2 mc 64 batch 64, fp32) RUN whole at full size (property checks: the full-size
 oracle is minutes of CPU, the per-layer / attention oracles at these shapes live in test_gpu_bench_shapes.py)."""
 import numpy as np
+import math
+
 import pytest
 import torch
 from torch import nn
@@ -263,3 +265,52 @@ def test_c3_whole_network_forward_vs_oracle_at_64_cubed():
     ebf = rel_l2(pbf[:1], ref)
     assert e32 < 1e-4 and ebf < 3e-2, (e32, ebf)
     assert rel_l2(pbf[:1], pbf0) < 2e-3           # the same sample alone (fused-statistics tiles are summed in another order)
+
+
+@pytest.mark.parametrize("train", [False, True], ids=["inference", "training"])
+def test_folded_skips_and_direct_ends_agree_with_the_unfused_plan(monkeypatch, train):
+    """The same bf16 network (3-D, mc 32 at 32^3: skips of 64 - 256 couts, 1-channel stem and head) planned with the round-3 fusions
+    (ResBlock skip inside the out-conv launch, stem / head as single launches) and without them: outputs agree to the bf16
+    rounding of the tensors that no longer exist (`sk`, the im2col / tap-partial intermediates), the fused plan launches fewer
+    kernels, and (training) every parameter gradient agrees - the backward graph of the fused plan is the unfused one."""
+    x = det_normal((2, 1, 32, 32, 32), "r3fsx").to(DEV)
+    t = torch.tensor([321, 45], device=DEV)
+    outs, kinds, grads = [], [], []
+    for on in ("1", "0"):
+        monkeypatch.setenv("RHO_FOLD_SKIP", on)
+        monkeypatch.setenv("RHO_DIRECT_ENDS", on)
+        model = _bench_unet(3, 32, 32, "bf16", False)
+        if train:
+            model.train()
+            pred = model(x, t)
+            (pred.float() ** 2).mean().backward()
+            grads.append({n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None})
+        else:
+            with torch.no_grad():
+                pred = model(x, t)
+        plan = next(iter(model.engine()._plans.values()))
+        kinds.append([i["kind"] for i in plan.info])
+        outs.append(pred.detach().float().clone())
+        del model, plan
+        torch.cuda.empty_cache()
+    assert torch.isfinite(outs[0]).all()
+    assert rel_l2(outs[0], outs[1]) < 1e-2, rel_l2(outs[0], outs[1])
+    fused, plain = kinds
+    assert fused.count("conv1") < plain.count("conv1")                      # the skip launches are gone
+    if not train:
+        assert "stem" in fused and "head" in fused and "tap_sum" not in fused and "pack" not in fused
+        assert "tap_sum" in plain and "stem" not in plain
+    else:
+        assert set(grads[0]) == set(grads[1])
+        gtot = math.sqrt(sum(float(g.double().norm()) ** 2 for g in grads[1].values()))
+        bad = []
+        for n in grads[0]:
+            a, b = grads[0][n].flatten().double(), grads[1][n].flatten().double()
+            if float(b.norm()) < 1e-4 * gtot:          # numerically zero (e.g. the key bias of an attention block): magnitude only
+                if float(a.norm()) > 1e-3 * gtot:
+                    bad.append((n, "should be ~0", float(a.norm()), float(b.norm())))
+                continue
+            c = float(torch.dot(a, b) / (a.norm() * b.norm()))
+            if c < 0.98 or abs(float(a.norm()) - float(b.norm())) > 0.1 * float(b.norm()):
+                bad.append((n, round(c, 4), float(a.norm()), float(b.norm())))
+        assert not bad, bad[:8]
