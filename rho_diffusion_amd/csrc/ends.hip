@@ -27,8 +27,7 @@ __global__ __launch_bounds__(256) void k_stem3d(const float* __restrict__ x, con
     constexpr int COUT = 32 * NCT;
     constexpr int ROWB = COUT * 2 + 16;               // staged output row pitch (bytes): odd number of 16-byte slots
     __shared__ float halo[HD * HH * HW];
-    __shared__ __attribute__((aligned(16))) char stg[256 * ROWB];
-    __shared__ float red[256 * 16];
+    __shared__ __attribute__((aligned(16))) char stg[256 * ROWB];      // (>= 20 KB: reused for the statistics reduction, 16 KB)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
     const int n = blockIdx.z, tiles = gridDim.x;
     const int bt = blockIdx.x;
@@ -118,6 +117,8 @@ __global__ __launch_bounds__(256) void k_stem3d(const float* __restrict__ x, con
     }
     if (stats != nullptr) {
         // threads tid = piece (mod PPR) hold partials of the same 8 channels: combined in thread order (reproducible)
+        float* const red = reinterpret_cast<float*>(stg);             // [256][16], over the staged tile every thread is done with
+        __syncthreads();
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             red[tid * 16 + e] = ssum[e];
