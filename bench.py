@@ -118,8 +118,10 @@ def labels_for(batch, device):
 
 
 def cpu_baseline(kw, ddpm, args):
-    """The CPU oracle (fp32, stock PyTorch CPU ops == what the reference executes) timed on this
-    host's cores for a bounded sample: B=1 denoising steps, scaled linearly to the bench batch."""
+    """The CPU oracle (fp32, stock PyTorch CPU ops == what the reference executes) timed on this host's cores for a bounded
+    sample, BOTH metrics: denoising steps and one training step (q_sample + forward + MSE + autograd
+    backward + torch.optim.AdamW, what scripts/training_ddp.py:185-206 executes).  Batch: the bench batch itself where a full-batch
+    step costs seconds (c1: B = 16, as BASELINE.md prescribes), else B = 1 scaled linearly in time."""
     from oracle import ref_torch as R
     try:
         avail = len(os.sched_getaffinity(0))
@@ -132,23 +134,58 @@ def cpu_baseline(kw, ddpm, args):
     sd = {k: v.detach().float().cpu() for k, v in ddpm.backbone.state_dict().items()}
     cfg = {k: v for k, v in kw.items() if k != "compute_dtype"}
     sched = R.linear_schedule(1000, 1e-3, 0.02)
-    shape = (1, 1) + (args.grid,) * args.dims
-    x = torch.randn(shape)
-    z = torch.randn(shape)
-    times = []
-    with torch.no_grad():
-        for i in range(args.cpu_steps + 1):
-            t0 = time.perf_counter()
-            t = 999 - i
-            yb = labels_for(1, "cpu") if args.labels else None
-            pred = R.unet_forward(sd, cfg, x, torch.full((1,), t, dtype=torch.long), yb, DEEP_GALAXY_SPACE if args.labels else None)
-            x = R.p_sample_step(x, pred, t, sched, z)
-            times.append(time.perf_counter() - t0)
-    per_b1 = sum(times[1:]) / max(1, len(times) - 1)
-    return {"value": 1.0 / (per_b1 * args.batch), "unit": "denoising_steps/s", "cores": n_threads, "host_cpu_count": os.cpu_count(),
-            "kind": "port",
-            "sample": f"B=1 of {args.batch}, {args.cpu_steps} timed steps after 1 warm-up ({per_b1:.2f} s per B=1 step), "
-                      f"scaled x{args.batch} in time; fp32 oracle (oracle/ref_torch.py)"}
+    space = DEEP_GALAXY_SPACE if args.labels else None
+
+    def sample_steps(bsz, n):
+        shape = (bsz, 1) + (args.grid,) * args.dims
+        x, z = torch.randn(shape), torch.randn(shape)
+        yb = labels_for(bsz, "cpu") if args.labels else None
+        times = []
+        with torch.no_grad():
+            for i in range(n):
+                t0 = time.perf_counter()
+                t = 999 - i
+                pred = R.unet_forward(sd, cfg, x, torch.full((bsz,), t, dtype=torch.long), yb, space)
+                x = R.p_sample_step(x, pred, t, sched, z)
+                times.append(time.perf_counter() - t0)
+        return times
+
+    warm = sample_steps(1, 1)[0]                    # (also the ATen warm-up)
+    bsz = args.batch if warm * args.batch <= 4.0 else 1
+    times = sample_steps(bsz, args.cpu_steps + (1 if bsz > 1 else 0))
+    per = sum(times[1:] if bsz > 1 else times) / max(1, len(times) - (1 if bsz > 1 else 0))
+    scale = args.batch // bsz
+    out = {"value": 1.0 / (per * scale), "unit": "denoising_steps/s", "cores": n_threads, "host_cpu_count": os.cpu_count(),
+           "kind": "port",
+           "sample": (f"B={bsz} of {args.batch}, {args.cpu_steps} timed steps after 1 warm-up ({per:.2f} s per B={bsz} step)"
+                      + (f", scaled x{scale} in time" if scale > 1 else ", the full batch") + "; fp32 oracle (oracle/ref_torch.py)")}
+    # ---- training: one optimizer step of the oracle (leaf copies of the weights, autograd through the functional forward)
+    if per * 3.5 > 75.0:
+        out["training"] = {"value": None, "unit": "training_samples/s",
+                           "sample": f"skipped: a B={bsz} oracle training step is ~{per * 3.5:.0f} s of host time here (forward {per:.1f} s)"}
+        return out
+    params = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    opt = torch.optim.AdamW([v for v in params.values() if v.requires_grad], lr=1e-4)
+    shape = (bsz, 1) + (args.grid,) * args.dims
+    x0 = torch.rand(shape) * 2 - 1
+    yb = labels_for(bsz, "cpu") if args.labels else None
+    n_train = 1 if per > 2.0 else 3                 # (>= 2 timed steps where a step is cheap: BASELINE.md section 3, c1)
+    tt = []
+    for i in range(n_train + (0 if per > 2.0 else 1)):
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        t = torch.randint(0, 1000, (bsz,))
+        eps = torch.randn(shape)
+        loss = R.training_loss(lambda x_, t_, y_: R.unet_forward(params, cfg, x_, t_, y_, space), x0, t, eps, sched["alpha_bar_t"], yb)
+        loss.backward()
+        opt.step()
+        tt.append(time.perf_counter() - t0)
+    tper = sum(tt[-n_train:]) / n_train
+    out["training"] = {"value": bsz / tper, "unit": "training_samples/s", "cores": n_threads, "kind": "port",
+                       "sample": (f"B={bsz} of {args.batch}: {n_train} timed step(s)" + ("" if per > 2.0 else " after 1 warm-up")
+                                  + f" of q_sample + forward + MSE + autograd backward + torch.optim.AdamW ({tper:.2f} s per step); "
+                                    "samples/s does not scale with the batch on the host, so the B=" + str(bsz) + " rate is the rate")}
+    return out
 
 
 def by_kind(prof):
@@ -188,6 +225,13 @@ def roofline_of(plan, args):
     if args.dump_ops:
         dump_ops(args.dump_ops, prof)
     peak = MFMA_PEAK_TFLOPS[args.dtype]
+    # `achieved` / `frac` = the algorithmic FLOPs of the dominant kind's OWN operator (conv3: the 27-tap count of the reference's
+    # conv_nd calls, 127.56 TFLOP per c3 step) / the summed durations of its launches - ONE quantity round to round.  The 1x1x1
+    # ResBlock skips that ride inside the same launches since round 3 are extra work done in that time: reported beside it
+    # (`folded_conv1_flops_per_step`, `frac_with_folded_conv1`), never inside `frac`.
+    folded = sum(p.get("folded_conv1_flops", 0.0) for p in sel)
+    fl_all = fl
+    fl = fl - folded
     achieved = fl / (ms * 1e-3) / 1e12
     # HBM traffic + MFMA utilisation of the same launches from PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
     # SQ_INSTS_MFMA: separate --pmc passes collected with rocprofv3 on this command, tests/gpu_pmc.sh -> tools/pmc_summary.py).
@@ -222,11 +266,12 @@ def roofline_of(plan, args):
     return {
         "bound": "mfma", "kernel": KIND_KERNEL[dom], "kind": dom,
         "achieved": achieved, "peak": peak,
-        "unit": "TFLOP/s", "frac": achieved / peak, "executed_frac": exe_tf / peak,
+        "unit": "TFLOP/s", "frac": achieved / peak, "frac_with_folded_conv1": fl_all / (ms * 1e-3) / 1e12 / peak,
+        "executed_frac": exe_tf / peak,
         "traffic": traffic, "traffic_source": traffic_note, "mfma_util": mfma_util,
         "build_id": build, "executed_flops_per_step": exe, "executed_TFLOPs": exe_tf,
         # ResBlock skip convolutions (1x1x1) contracted inside their out-conv's launch (inference plans): part of the figures above
-        "folded_conv1_flops_per_step": sum(p.get("folded_conv1_flops", 0.0) for p in sel),
+        "folded_conv1_flops_per_step": folded,
         "algorithmic_bytes_per_launch": alg_bytes / max(1, len(sel)), "algorithmic_flops_per_launch": fl / max(1, len(sel)),
         "launches_per_step": len(sel), "avg_launch_ms": ms / max(1, len(sel)),
         "algorithmic_bytes_per_step": alg_bytes, "algorithmic_flops_per_step": fl, "kernel_ms_per_step": ms,
@@ -234,9 +279,42 @@ def roofline_of(plan, args):
         "by_kind_ms": {k: round(v["ms"], 3) for k, v in kinds.items()},
         "by_kind_TFLOPs": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in kinds.items() if v["flops"] > 0 and v["ms"] > 0
                            and k in ("conv3", "conv1", "attention")},
-        "hbm_kernels_GBps": {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in kinds.items()
-                             if k in ("gn_partial", "pack") and v["ms"] > 0},
+        "hbm_kernels_GBps": hbm_kinds(kinds),
     }
+
+
+HBM_KINDS = ("gn_partial", "gn_apply", "pack", "stem", "head", "resample", "gn_bwd_reduce", "gn_bwd_apply", "add", "chan_sum", "pool2x",
+             "upsample", "avgpool_bwd")
+
+
+def hbm_kinds(kinds):
+    """HBM-regime launches of a plan (GroupNorm / elementwise passes): algorithmic bytes / summed HIP-event time, and
+    the fraction of the 8 TB/s HBM3E peak."""
+    out = {}
+    for k, v in kinds.items():
+        if k in HBM_KINDS and v["ms"] > 0 and v["bytes"] > 0:
+            gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+            out[k] = {"GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 3), "ms": round(v["ms"], 3), "launches": v["launches"]}
+    return out
+
+
+def hbm_pipeline_kernels(fns):
+    """The pipeline's own elementwise kernels (q_sample, p_sample, Philox, MSE, AdamW, ...): {name: (callable, algorithmic bytes)}
+    -> {name: {GBps, frac, ms}} with a HIP-event pair around 5 back-to-back launches on the launch stream."""
+    out = {}
+    for name, (fn, nbytes) in fns.items():
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        out[name] = {"GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 3), "ms": round(ms, 4), "bytes": int(nbytes)}
+    return out
 
 
 def launch_self(args) -> int:
@@ -290,6 +368,8 @@ def main():
         ranks_counted = int(round(float(w[0].item())))
         assert ranks_counted == world, f"process group reduced over {ranks_counted} ranks, expected {world}"
 
+    rank_spread = {}
+
     def timed(step_fn, steps, warmup):
         """(wall seconds for `steps` steps, max over ranks; per-step HIP-event durations in ms on this rank).  The events sit on
         the stream the step is launched on; recording them costs nothing measurable against a >= 1 ms step."""
@@ -305,10 +385,17 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+        rank_spread.clear()
         if world > 1:
-            tt = torch.tensor([dt], device=device, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
+            # every rank's own wall time for the K steps: the maximum is the job's time (the contract); minimum and maximum
+            # are both reported so that a straggling rank is visible in the line
+            mine = torch.tensor([dt], device=device, dtype=torch.float64)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank = [float(t_.item()) for t_ in allr]
+            dt = max(per_rank)
+            rank_spread.update(min=1e3 * min(per_rank) / steps, max=1e3 * max(per_rank) / steps,
+                               slowest_rank=per_rank.index(max(per_rank)))
         med = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
         return dt, med
 
@@ -342,9 +429,20 @@ def main():
                 print(f"[bench] HIP graph capture failed ({type(exc).__name__}: {exc}); eager launches", file=sys.stderr)
         dt, med = timed(step_fn, args.steps, args.warmup)
         assert torch.isfinite(x_t).all(), "non-finite state after the timed steps"
-        results["sample"] = dict(dt=dt, steps=args.steps, graphed=graphed, median_ms=med)
+        results["sample"] = dict(dt=dt, steps=args.steps, graphed=graphed, median_ms=med, rank_ms=dict(rank_spread))
+        hbm_pipe = {}
         if rank == 0 and not args.no_roofline:
             roofline = roofline_of(next(iter(engine._plans.values())), args)
+            # the step's own HBM-regime kernels: bytes / HIP-event time against the 8 TB/s peak.  t_dev is parked at 500
+            # (a mid-chain step: noise term on) and restored, so the state stays finite
+            t_save = t_dev.clone()
+            t_dev.fill_(500)
+            xs, pred_ = x_t.clone(), torch.zeros_like(x_t)
+            hbm_pipe.update(hbm_pipeline_kernels({
+                "k_philox_normal": (lambda: ops.philox_normal(z, ddpm.noise_seed, 0, offset_dev=off_dev), 4.0 * n_elem),
+                "k_p_sample": (lambda: ops.p_sample_step(xs, pred_, z, tables["coef"], t_dev), 16.0 * n_elem)}))
+            t_dev.copy_(t_save)
+            del xs, pred_
 
     if args.mode in ("ddim", "both"):
         # the GaussianDiffusionPipeline step (x0-prediction UNet + dynamic thresholding + DDIM eta = 0),
@@ -400,7 +498,7 @@ def main():
         tsteps = args.train_steps or args.steps
         dt, med = timed(train_step, tsteps, max(1, args.warmup))
         assert torch.isfinite(last["loss"]).all(), "non-finite training loss"
-        results["train"] = dict(dt=dt, steps=tsteps, loss=float(last["loss"].detach()), median_ms=med,
+        results["train"] = dict(dt=dt, steps=tsteps, loss=float(last["loss"].detach()), median_ms=med, rank_ms=dict(rank_spread),
                                 peak_mem_gb=round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
                                 plan_gb=round(engine._last_train_plan.nbytes() / 2 ** 30, 1))
         if rank == 0 and not args.no_roofline:
@@ -430,6 +528,50 @@ def main():
                                                             if v["flops"] > 0 and v["ms"] > 0}}
             if roofline is None:
                 roofline = roofline_of(tp, args)
+            results["train"]["hbm_kernels_GBps"] = {**{f"fwd.{k}": v for k, v in hbm_kinds(fk).items()},
+                                                    **{f"bwd.{k}": v for k, v in hbm_kinds(bk).items()}}
+            n_el = data.numel()
+            tq = torch.randint(0, 1000, (B,), device=device, dtype=torch.int64)
+            xq, eq = data.float().contiguous(), torch.randn_like(data, dtype=torch.float32)
+            oq = torch.empty_like(xq)
+            ar = trainer.opt.build_arena()[0]
+            sc = [torch.zeros_like(ar["flat"]) for _ in range(4)]        # scratch copies: the measurement must not move the weights
+            results["train"]["hbm_kernels_GBps"].update(hbm_pipeline_kernels({
+                "k_q_sample": (lambda: ops.q_sample(xq, eq, tq, tables["alpha_bar"], out=oq), 12.0 * n_el),
+                "k_mse": (lambda: ops.mse(xq, eq, want_grad=True), 12.0 * n_el),
+                "k_adamw": (lambda: ops.adamw(sc[0], sc[1], sc[2], sc[3], 1e-4, 0.9, 0.999, 1e-8, 1e-2, 1), 28.0 * sc[0].numel())}))
+            del sc, xq, eq, oq
+            # ---- DP overlap budget: where in the backward each gradient bucket closes, from HIP events on the
+            # launch stream - the window its RCCL all-reduce has before the optimizer needs it.  Nothing is sent at N = 1.
+            trainer.reducer.trace = []
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            trainer.opt.zero_grad()
+            loss_ = ddpm.training_step(batch)
+            e0.record()
+            loss_.backward()
+            e1.record()
+            trainer.reducer.finish()
+            trainer.opt.step()
+            e2.record()
+            torch.cuda.synchronize()
+            tr_, trainer.reducer.trace = trainer.reducer.trace, None
+            bwd_ms = e0.elapsed_time(e1)
+            closes = [(b_, nb_, e0.elapsed_time(ev_)) for b_, nb_, ev_ in tr_]
+            bw_assumed = 100.0                                            # GB/s of all-reduce bus bandwidth per ring: an ASSUMPTION
+            end_prev, fin = 0.0, []
+            for b_, nb_, tc_ in closes:
+                st_ = max(tc_, end_prev)
+                end_prev = st_ + nb_ / (bw_assumed * 1e9) * 1e3 * 2.0 * 7 / 8    # ring all-reduce moves 2 (N-1)/N of the bytes, N = 8
+                fin.append(end_prev)
+            results["train"]["ddp_overlap"] = {
+                "what": "bucket close times inside one backward (HIP events on the launch stream, N=1: nothing sent); the modelled "
+                        f"finish assumes {bw_assumed:.0f} GB/s ring bus bandwidth at N=8 (unmeasured: no 8-GPU node yet)",
+                "backward_ms": round(bwd_ms, 2), "buckets": len(closes),
+                "bucket_MB": [round(nb_ / 2 ** 20, 1) for _, nb_, _ in closes],
+                "close_ms_after_backward_start": [round(tc_, 2) for _, _, tc_ in closes],
+                "window_ms_before_backward_end": [round(bwd_ms - tc_, 2) for _, _, tc_ in closes],
+                "modelled_allreduce_finish_ms": [round(f_, 2) for f_ in fin],
+                "modelled_exposed_ms": round(max(0.0, (fin[-1] if fin else 0.0) - bwd_ms), 2)}
             del tp, bprof
         if not args.no_checkpoint_leg:
             # the same step with use_checkpoint=True on every ResBlock (reference: layers.py:153-199, unet_v2.py:266-271): activated
@@ -438,8 +580,7 @@ def main():
             for m_ in ddpm.backbone.modules():
                 if isinstance(m_, ResBlock):
                     m_.use_checkpoint = True
-            engine._plans = {k_: v_ for k_, v_ in engine._plans.items() if not k_[2]}       # drop the training plans: rebuilt with the flag
-            engine._last_train_plan = None
+            engine.drop_plans(train_only=True)     # free the 70+ GB of the materialising plan first (the flags are part of the plan key)
             import gc
             gc.collect()
             torch.cuda.empty_cache()
@@ -474,6 +615,8 @@ def main():
     }
     if "sample" in results:
         out["config"]["hip_graph"] = bool(results["sample"].get("graphed"))
+        if results["sample"].get("rank_ms"):
+            out["ms_per_step_per_rank"] = results["sample"]["rank_ms"]
         out["ms_per_step_hipevent_median"] = results["sample"]["median_ms"]
         out["config"]["sample_steps_per_sec"] = world * B * results["sample"]["steps"] / results["sample"]["dt"]
     if "ddim" in results:
@@ -489,7 +632,7 @@ def main():
         r = results["train"]
         out["training"] = {"metric": "training_samples_per_sec", "value": world * B * r["steps"] / r["dt"], "unit": "samples/s",
                            "steps": r["steps"], "ms_per_step": 1e3 * r["dt"] / r["steps"], "ms_per_step_hipevent_median": r["median_ms"],
-                           "loss": r["loss"],
+                           "loss": r["loss"], **({"ms_per_step_per_rank": r["rank_ms"]} if r.get("rank_ms") else {}),
                            "peak_mem_gb": r.get("peak_mem_gb"), "plan_gb": r.get("plan_gb"),
                            "step": "q_sample + UNetv2 fwd + MSE + bwd + "
                                    + ((("RCCL" if dist.get_backend() == "nccl" else dist.get_backend()) + " grad all-reduce + ") if world > 1 else "")
@@ -497,13 +640,22 @@ def main():
 
     if roofline is not None:
         out["roofline"] = roofline
+        if "sample" in results and hbm_pipe:
+            roofline["hbm_kernels_GBps"].update(hbm_pipe)
     if "train" in results and results["train"].get("use_checkpoint"):
         out["training"]["use_checkpoint"] = results["train"]["use_checkpoint"]
     if "train" in results and results["train"].get("breakdown"):
         out["training"]["by_kind_ms"] = results["train"]["breakdown"]
         out["training"]["roofline"] = results["train"]["roofline"]
+        out["training"]["roofline"]["hbm_kernels_GBps"] = results["train"].get("hbm_kernels_GBps", {})
+        if results["train"].get("ddp_overlap"):
+            out["training"]["ddp_overlap"] = results["train"]["ddp_overlap"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(kw, ddpm, args)
+    elif rank == 0 and world > 1:
+        # the CPU oracle is timed by the N = 1 run only (the contract: rank 0 at N = 1); the multi-GPU line points at it
+        out["cpu_baseline"] = {"value": None, "kind": "port", "sample": "see the N=1 line of this bench (python bench.py --gpus 1): "
+                               "the CPU oracle is timed there, on rank 0's host cores"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

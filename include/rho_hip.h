@@ -37,7 +37,7 @@ extern "C" {
 /* ABI version: bumped on ANY signature / struct-layout change (2: table_len in rho_q_sample(_coef), fmt in rho_gn_bwd_finalize,
  * rho_conv_desc grew; 3: round-3 additions).  A loader must compare rho_abi_version() with the header it was written against
  * before calling anything else (hip.py does; a build with all symbols but older signatures would be called with shifted arguments). */
-#define RHO_ABI_VERSION 6
+#define RHO_ABI_VERSION 7
 int rho_abi_version(void);
 /* static string: target arch + build flags */
 const char* rho_build_info(void);
@@ -76,6 +76,21 @@ int rho_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset,
 /* mean((a-b)^2) -> loss[0] (float32, zeroed by this call) and optionally grad_a = 2(a-b)/n.
  * replaces nn.MSELoss at ddpm.py:280 (+ its backward). */
 int rho_mse(const float* a, const float* b, float* loss, float* grad_a, int64_t n, void* stream);
+
+/* The same with an ORDERED reduction (ABI 7): block partials go to partials[n_partials] (scratch, >= 1; 1024 is plenty) and are added
+ * in index order, so the loss value is bit-reproducible run to run (rho_mse adds its blocks with an fp32 atomic, in arrival order).
+ * grad_a is identical in both.  The Python binding always uses this form. */
+int rho_mse_ws(const float* a, const float* b, float* loss, float* grad_a, int64_t n, float* partials, int64_t n_partials, void* stream);
+
+/* mean over all non-batch axes of a float32 [batch, per_sample] tensor -> out[batch]: mean_flat of layers.py:105-110 (ABI 7). */
+int rho_mean_flat(const float* x, float* out, int64_t batch, int64_t per_sample, void* stream);
+
+/* Reproducibility switch (ABI 7).  The reference's CPU path is deterministic; here three backward kernels combine partial sums
+ * with fp32 atomics by default (weight gradient, the dx of rho_linear_bwd, rho_multi_embed_bwd), so gradients differ in the last
+ * bits run to run.  rho_set_deterministic(1) (or RHO_DETERMINISTIC=1 / RHO_WGRAD_DETERMINISTIC=1 in the environment) makes the
+ * latter two take ordered paths and tells callers to use rho_conv_nd_wgrad_ws for the weight gradient; returns the old value. */
+int rho_set_deterministic(int on);
+int rho_get_deterministic(void);
 
 /* Fused multi-tensor-free AdamW over one flat float32 parameter arena
  * (torch.optim.AdamW built at abstract_diffusion.py:103-119): decoupled weight decay,
@@ -289,9 +304,13 @@ int rho_stem_conv3d(const float* x, const void* w, const float* bias, void* y, f
 int rho_head_conv3d(const void* x, const float* pre_a, const float* pre_b, int pre_silu, const void* w, const float* bias, float* out,
                     int64_t n, int64_t d, int64_t h, int64_t w_, int64_t c, void* stream);
 
-/* Workspace the k-split of `desc` wants (rho_conv_desc.ws), in bytes; 0 when the launch would not be split (3-D and 1x1x1 kernels,
- * phased / channel-major outputs, grids that already fill the chip).  Depends on geometry only: one allocation of the maximum over
- * a plan's descriptors serves all of them (launches on one stream are ordered). */
+/* Workspace the k-split of `desc` wants (rho_conv_desc.ws), in bytes; 0 when the launch would not be split: kernels with a depth
+ * extent (kd = 3: the batch is grid z there), launches with fused output statistics or channel-major outputs, grids of more than
+ * 128 workgroups, fewer than 4 input-channel chunks.  Every kd = 1 launch qualifies otherwise - INCLUDING 1x1x1 launches (also the
+ * qkv / proj_out projections of a 3-D model on a small grid).  Size = splits (<= 16) x positions x coutp x 4 bytes; at most
+ * 128 workgroups x 256 positions x 128 couts x 16 splits x 4 B = 268 MB.  Depends on geometry only: one allocation of the maximum
+ * over a plan's descriptors serves all of them (launches on one stream are ordered); a plan keeps it for its lifetime (counted by
+ * _Plan.nbytes(); 64 MB at BASELINE configs[0], 0 at configs[2] - every grid there fills the chip). */
 int64_t rho_conv_workspace_bytes(const rho_conv_desc* desc);
 
 /* Test / profiling aid: the name of the kernel instantiation rho_conv_nd_fwd would launch for `desc`
@@ -339,6 +358,15 @@ int rho_ema_update(float* shadow, const float* param, int64_t n, float one_minus
  * bias gradient = per-channel sums of dy over all positions (the dY tiles pass through the kernel anyway; this replaces
  * a separate rho_chan_sum read of dy). */
 int rho_conv_nd_wgrad(const rho_conv_desc* desc, const void* dy, int64_t dy_width, float* dw, float* dbias, void* stream);
+
+/* Deterministic form of rho_conv_nd_wgrad (ABI 7): every workgroup (or wave, where the waves of a workgroup split positions) STORES its
+ * partial [taps][coutp][cin] (+ [coutp] channel sums) to a slab of its own in `ws`, and a second launch adds the slabs to dw / dbias
+ * in slab order - the same values as the atomic flush up to the summation order, bit-identical run to run and across replicas.
+ * ws: scratch of at least rho_conv_wgrad_workspace_bytes(desc, dy_width) bytes (170 - 340 MB per layer at BASELINE configs[2]);
+ * costs one write + one read of it per launch (about +1.5 % per training step there). */
+int rho_conv_nd_wgrad_ws(const rho_conv_desc* desc, const void* dy, int64_t dy_width, float* dw, float* dbias, void* ws,
+                         int64_t ws_bytes, void* stream);
+int64_t rho_conv_wgrad_workspace_bytes(const rho_conv_desc* desc, int64_t dy_width);
 
 /* As rho_conv_variant, for the kernel rho_conv_nd_wgrad would launch ("k_wgrad<bf16,3,3,3,MAXP=10>", "k_wgrad1<bf16>"). */
 int rho_conv_wgrad_variant(const rho_conv_desc* desc, int64_t dy_width, char* buf, int cap);

@@ -1,6 +1,8 @@
 // HBM-bound kernels of the DDPM loops and the small embedding GEMVs.
 // Each kernel is a grid-stride loop over 16-byte-per-lane accesses (coalesced 1 KiB per wave
 // instruction), grid capped at 256 CUs x 8 blocks.
+#include <cstdlib>
+
 #include "common.h"
 
 static inline int grid_for(int64_t work_items, int block) {
@@ -11,6 +13,24 @@ static inline int grid_for(int64_t work_items, int block) {
 }
 
 extern "C" int rho_abi_version(void) { return RHO_ABI_VERSION; }
+
+// Process-wide reproducibility switch (RHO_DETERMINISTIC=1, or rho_set_deterministic): kernels that combine partial sums with
+// fp32 atomics (linear backward, label-embedding backward) take an ordered path instead; the weight gradient's ordered flush
+// needs a workspace and is chosen by the caller (rho_conv_nd_wgrad_ws), who reads this flag.
+static int g_deterministic = -1;
+extern "C" int rho_get_deterministic(void) {
+    if (g_deterministic < 0) {
+        const char* e = getenv("RHO_DETERMINISTIC");
+        const char* e2 = getenv("RHO_WGRAD_DETERMINISTIC");
+        g_deterministic = ((e && atoi(e) != 0) || (e2 && atoi(e2) != 0)) ? 1 : 0;
+    }
+    return g_deterministic;
+}
+extern "C" int rho_set_deterministic(int on) {
+    const int old = rho_get_deterministic();
+    g_deterministic = on ? 1 : 0;
+    return old;
+}
 #ifndef RHO_BUILD_ID
 #define RHO_BUILD_ID "unstamped"
 #endif
@@ -221,6 +241,58 @@ extern "C" int rho_mse(const float* a, const float* b, float* loss, float* grad_
     hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), as_stream(stream));
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k_mse, dim3(grid_for(n, 256 * 8)), dim3(256), 0, as_stream(stream), a, b, loss, grad_a, n, 1.0f / (float)n);
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
+// Ordered form: block b stores its partial to partials[b]; one wave adds them in index order -> the loss is bit-reproducible
+// (the atomic form above adds the blocks in arrival order).  grad is the same either way.
+__global__ __launch_bounds__(256) void k_mse_part(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ partials,
+                                                  float* __restrict__ grad, int64_t n, float inv_n) {
+    __shared__ float red[4];
+    float acc = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = a[i] - b[i];
+        acc += d * d;
+        if (grad) grad[i] = 2.0f * d * inv_n;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;
+}
+__global__ __launch_bounds__(64) void k_mse_final(const float* __restrict__ partials, int np, float* __restrict__ loss) {
+    float acc = 0.0f;
+    for (int i = threadIdx.x; i < np; i += 64) acc += partials[i];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) *loss = acc;
+}
+
+extern "C" int rho_mse_ws(const float* a, const float* b, float* loss, float* grad_a, int64_t n, float* partials, int64_t n_partials,
+                          void* stream) {
+    if (!a || !b || !loss || !partials || n <= 0 || n_partials < 1) return RHO_E_ARG;
+    int64_t g = grid_for(n, 256 * 8);
+    if (g > n_partials) g = n_partials;
+    hipLaunchKernelGGL(k_mse_part, dim3((unsigned)g), dim3(256), 0, as_stream(stream), a, b, partials, grad_a, n, 1.0f / (float)n);
+    hipLaunchKernelGGL(k_mse_final, dim3(1), dim3(64), 0, as_stream(stream), partials, (int)g, loss);
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
+// mean over all non-batch axes (layers.py:105-110, mean_flat): one workgroup per sample, fp32 in a fixed order
+__global__ __launch_bounds__(256) void k_mean_flat(const float* __restrict__ x, float* __restrict__ out, int64_t per_sample) {
+    __shared__ float red[4];
+    const float* xs = x + (int64_t)blockIdx.x * per_sample;
+    float acc = 0.0f;
+    for (int64_t i = threadIdx.x; i < per_sample; i += 256) acc += xs[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)per_sample;
+}
+extern "C" int rho_mean_flat(const float* x, float* out, int64_t batch, int64_t per_sample, void* stream) {
+    if (!x || !out || batch <= 0 || per_sample <= 0 || batch > 0x7FFFFFFF) return RHO_E_ARG;
+    hipLaunchKernelGGL(k_mean_flat, dim3((unsigned)batch), dim3(256), 0, as_stream(stream), x, out, per_sample);
     RHO_LAUNCH_CHECK();
     return 0;
 }
@@ -901,6 +973,24 @@ __global__ __launch_bounds__(256) void k_linear_bwd_x(const float* __restrict__ 
     atomicAdd(dx + i, acc);
 }
 
+// ordered form (rho_get_deterministic): one thread walks all of out_dim in index order - no atomics, 0.2-0.4 ms per FiLM linear
+__global__ __launch_bounds__(256) void k_linear_bwd_x_det(const float* __restrict__ dout, const float* __restrict__ w,
+                                                          const float* __restrict__ x, float* __restrict__ dx, int batch, int in_dim,
+                                                          int out_dim, int act_in, int64_t dstride, int acc_dx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)batch * in_dim) return;
+    const int b = (int)(i / in_dim), k = (int)(i % in_dim);
+    float acc = 0.0f;
+#pragma unroll 8
+    for (int o = 0; o < out_dim; ++o) acc = fmaf(dout[(int64_t)b * dstride + o], w[(int64_t)o * in_dim + k], acc);
+    if (act_in) {
+        const float u = x[i];
+        const float s = 1.0f / (1.0f + expf(-u));
+        acc *= s * (1.0f + u * (1.0f - s));
+    }
+    dx[i] = acc_dx ? dx[i] + acc : acc;
+}
+
 extern "C" int rho_linear_bwd(const float* dout, int64_t dout_stride, const float* x, const float* w, float* dw, float* db,
                               float* dx, int64_t batch, int64_t in_dim, int64_t out_dim, int act_in, int acc_params, int acc_dx,
                               void* stream) {
@@ -910,7 +1000,10 @@ extern "C" int rho_linear_bwd(const float* dout, int64_t dout_stride, const floa
         hipLaunchKernelGGL(k_linear_bwd_w, dim3((unsigned)((out_dim * in_dim + 255) / 256)), dim3(256), 0, as_stream(stream), dout, x, dw,
                            db, (int)batch, (int)in_dim, (int)out_dim, act_in, acc_params, dstride);
     }
-    if (dx) {
+    if (dx && rho_get_deterministic()) {
+        hipLaunchKernelGGL(k_linear_bwd_x_det, dim3((unsigned)((batch * in_dim + 255) / 256)), dim3(256), 0, as_stream(stream), dout, w, x,
+                           dx, (int)batch, (int)in_dim, (int)out_dim, act_in, dstride, acc_dx);
+    } else if (dx) {
         if (!acc_dx) {
             hipError_t e = hipMemsetAsync(dx, 0, (size_t)batch * in_dim * sizeof(float), as_stream(stream));
             if (e != hipSuccess) return (int)e;

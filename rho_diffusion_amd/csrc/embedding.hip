@@ -137,11 +137,29 @@ __global__ __launch_bounds__(256) void k_multi_embed_bwd(const float* __restrict
     for (int d = threadIdx.x; d < dim; d += 256) atomicAdd(row + d, demb[(int64_t)b * dim + d]);
 }
 
+// ordered form (rho_get_deterministic): one block per key walks the batch in index order
+__global__ __launch_bounds__(256) void k_multi_embed_bwd_det(const float* __restrict__ demb, const int32_t* __restrict__ idx,
+                                                             float* const* dtables, int nkeys, int dim, int batch) {
+    const int i = blockIdx.x;
+    for (int b = 0; b < batch; ++b) {
+        const int j = idx[(int64_t)b * nkeys + i];
+        if (j < 0) continue;
+        float* const row = dtables[i] + (int64_t)j * dim;
+        for (int d = threadIdx.x; d < dim; d += 256) row[d] += demb[(int64_t)b * dim + d];     // (a thread owns its d: ordered in b)
+    }
+}
+
+extern "C" int rho_get_deterministic(void);
+
 extern "C" int rho_multi_embed_bwd(const float* demb, const int32_t* idx, float* const* dtables, int64_t nkeys, int64_t batch,
                                    int64_t dim, void* stream) {
     if (!demb || !idx || !dtables || nkeys <= 0 || nkeys > 16 || batch <= 0 || dim <= 0) return RHO_E_ARG;
-    hipLaunchKernelGGL(k_multi_embed_bwd, dim3((unsigned)batch, (unsigned)nkeys), dim3(256), 0, as_stream(stream), demb, idx, dtables,
-                       (int)nkeys, (int)dim);
+    if (rho_get_deterministic())
+        hipLaunchKernelGGL(k_multi_embed_bwd_det, dim3((unsigned)nkeys), dim3(256), 0, as_stream(stream), demb, idx, dtables, (int)nkeys,
+                           (int)dim, (int)batch);
+    else
+        hipLaunchKernelGGL(k_multi_embed_bwd, dim3((unsigned)batch, (unsigned)nkeys), dim3(256), 0, as_stream(stream), demb, idx, dtables,
+                           (int)nkeys, (int)dim);
     RHO_LAUNCH_CHECK();
     return 0;
 }

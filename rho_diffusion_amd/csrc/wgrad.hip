@@ -49,7 +49,26 @@ struct WgradK {
     int pad_h, pad_w, oy_mul, oy_add, ox_mul, ox_add, Ho_out, Wo_out;
     int xcd_map;        // 1: workgroups of one position slab (all cout tiles x cin chunks) on consecutive launch slots of one XCD
     int pairc;          // f32 1x1x1: a workgroup owns TWO 16-channel input chunks (the upper 16 B columns of the MFMA carry the second)
+    // Deterministic flush (rho_conv_nd_wgrad_ws): instead of fp32 atomics into dw / dbias (whose arrival order differs run to run)
+    // every accumulator owner STORES its partial tile to its own slab [taps][coutp][cin] + [coutp]; k_wgrad_slab_reduce then adds
+    // the slabs in slab order.  Owner = the position slab of the workgroup (bx), x 4 + wave where the waves split positions.
+    float* slab;
+    long long slab_stride;      // floats per slab (taps * coutp * cin + coutp)
+    long long slab_bias_off;    // offset of the bias partial inside a slab (taps * coutp * cin)
 };
+
+// one element of a workgroup's partial weight gradient: ordered slab store (deterministic mode) or fp32 atomic
+// (base = the owner's slab or dw: resolved once per flush from the kernel-argument segment, see RHO_WG_FLUSH_ARGS)
+__device__ __forceinline__ void wg_flush(bool det, float* base, size_t off, float v) {
+    if (det) base[off] = v;
+    else atomicAdd(base + off, v);
+}
+// The flush parameters are read from the kernel-argument segment AFTER the tile loop: held in SGPRs across it they pushed the
+// main bf16 variant past the scalar register file (8 spills to VGPR lanes).  The empty asm keeps the reload below the loop.
+#define RHO_WG_FLUSH_ARGS()                                                                                                          \
+    const __attribute__((address_space(4))) WgradK* qp_ = (const __attribute__((address_space(4))) WgradK*)__builtin_amdgcn_kernarg_segment_ptr(); \
+    asm volatile("" : "+s"(qp_));                                                                                                    \
+    const __attribute__((address_space(4))) WgradK& kq = *qp_
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
@@ -617,11 +636,23 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
             float accv = 0.0f;
             for (int q = 0; q < 32; ++q) accv += red[(q * 8 + piece) * DPE + e];
             const int co = co0 + piece * DPE + e;
-            if (co < p.dyw && co < p.coutp) atomicAdd(p.dbias + co, accv);
+            RHO_WG_FLUSH_ARGS();
+            if (kq.slab != nullptr) {
+                // (where the waves own slabs of their own, the workgroup's channel sums go to the first and zeros to the rest)
+                if (co < kq.coutp) {
+                    float* const bs = kq.slab + (size_t)(TAPSPLIT ? bx : bx * 4) * (size_t)kq.slab_stride + (size_t)kq.slab_bias_off + co;
+                    bs[0] = co < kq.dyw ? accv : 0.0f;
+                    if constexpr (!TAPSPLIT) { bs[kq.slab_stride] = 0.0f; bs[2 * kq.slab_stride] = 0.0f; bs[3 * kq.slab_stride] = 0.0f; }
+                }
+            } else if (co < kq.dyw && co < kq.coutp) atomicAdd(kq.dbias + co, accv);
         }
     }
 
     // ---- flush: lane holds ci = c + (lane&31), rows co0 + 32*mi + (r&3) + 8*(r>>2) + 4*half
+    // (deterministic mode: slab of this accumulator's owner - the workgroup, or the wave where waves split the positions of a tile)
+    RHO_WG_FLUSH_ARGS();
+    const bool fdet = kq.slab != nullptr;
+    float* const fbase = fdet ? kq.slab + (size_t)(TAPSPLIT ? bx : bx * 4 + wave) * (size_t)kq.slab_stride : kq.dw;
     if constexpr (IS_BF16) {
         const int ci = c + (lane & 31);
 #pragma unroll
@@ -632,7 +663,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int co = co0 + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        if (co < p.coutp) atomicAdd(p.dw + ((size_t)tap_of[ti] * p.coutp + co) * p.cin + ci, acc[ti][mi][r]);
+                        if (co < kq.coutp) wg_flush(fdet, fbase, ((size_t)tap_of[ti] * kq.coutp + co) * kq.cin + ci, acc[ti][mi][r]);
                     }
             }
         }
@@ -649,7 +680,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (co < p.coutp) atomicAdd(p.dw + ((size_t)tap * p.coutp + co) * p.cin + cif, acc[s_][0][r]);
+                    if (co < kq.coutp) wg_flush(fdet, fbase, ((size_t)tap * kq.coutp + co) * kq.cin + cif, acc[s_][0][r]);
                 }
             }
         }
@@ -782,7 +813,8 @@ __global__ __launch_bounds__(256) void k_wgrad1(const WgradK p, long long npos, 
             float accv = 0.0f;
             for (int qq = 0; qq < 32; ++qq) accv += red[(qq * 8 + piece) * 8 + e];
             const int co = co0 + piece * 8 + e;
-            if (co < p.dyw && co < p.coutp) atomicAdd(p.dbias + co, accv);
+            if (p.slab != nullptr) { if (co < p.coutp) p.slab[(size_t)bx * (size_t)p.slab_stride + (size_t)p.slab_bias_off + co] = co < p.dyw ? accv : 0.0f; }
+            else if (co < p.dyw && co < p.coutp) atomicAdd(p.dbias + co, accv);
         }
     }
     if (wave < nchunk) {
@@ -792,7 +824,7 @@ __global__ __launch_bounds__(256) void k_wgrad1(const WgradK p, long long npos, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (co < p.coutp) atomicAdd(p.dw + (size_t)co * p.cin + ci, acc[mi][r]);
+                if (co < p.coutp) wg_flush(p.slab != nullptr, p.slab != nullptr ? p.slab + (size_t)bx * (size_t)p.slab_stride : p.dw, (size_t)co * p.cin + ci, acc[mi][r]);
             }
     }
 }
@@ -855,11 +887,47 @@ inline int ilog2(int v) {
 // (channels-last, row width dy_width >= cout, extra channels must be zero); dw is an fp32 buffer
 // [taps][coutp][c1+c2] that this call ACCUMULATES into (zero it first).  up_h/up_w are not supported:
 // materialise the upsampled input (rho_upsample2x) and pass it as x1.
-static int wgrad_impl(const rho_conv_desc* dp, const void* dy, int64_t dy_width, float* dw, float* dbias, void* stream);
+static int wgrad_impl(const rho_conv_desc* dp, const void* dy, int64_t dy_width, float* dw, float* dbias, void* stream,
+                      float* ws = nullptr, int64_t ws_bytes = 0, int64_t* ws_want = nullptr);
 
 extern "C" int rho_conv_nd_wgrad(const rho_conv_desc* dp, const void* dy, int64_t dy_width, float* dw, float* dbias, void* stream) {
     if (!dp || !dy || !dw) return RHO_E_ARG;
     return wgrad_impl(dp, dy, dy_width, dw, dbias, stream);
+}
+
+// Deterministic form: the same launch, flushed through ordered slabs in `ws` instead of fp32 atomics (bit-reproducible run to run
+// and across data-parallel replicas).  ws must hold rho_conv_wgrad_workspace_bytes(desc, dy_width) bytes; it is scratch.
+extern "C" int rho_conv_nd_wgrad_ws(const rho_conv_desc* dp, const void* dy, int64_t dy_width, float* dw, float* dbias, void* ws,
+                                    int64_t ws_bytes, void* stream) {
+    if (!dp || !dy || !dw || !ws || ws_bytes <= 0) return RHO_E_ARG;
+    return wgrad_impl(dp, dy, dy_width, dw, dbias, stream, (float*)ws, ws_bytes);
+}
+
+extern "C" int64_t rho_conv_wgrad_workspace_bytes(const rho_conv_desc* dp, int64_t dy_width) {
+    if (!dp) return 0;
+    int64_t b = 0;
+    return wgrad_impl(dp, nullptr, dy_width, nullptr, nullptr, nullptr, nullptr, 0, &b) == 0 ? b : 0;
+}
+
+// dw[i] (+ dbias) += slab[0][i] + slab[1][i] + ... in slab order: the fixed summation order of the deterministic flush
+__global__ __launch_bounds__(256) void k_wgrad_slab_reduce(const float* __restrict__ slab, int nslab, long long stride, float* __restrict__ dw,
+                                                           long long nw, float* __restrict__ dbias, int nb) {
+    const long long total = nw + (dbias ? nb : 0);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        float* dst = i < nw ? dw + i : dbias + (i - nw);
+        float v = *dst;
+        const float* sp = slab + i;
+        for (int s_ = 0; s_ < nslab; ++s_) v += sp[(long long)s_ * stride];
+        *dst = v;
+    }
+}
+
+static int launch_slab_reduce(const float* ws, int nslab, long long stride, float* dw, long long nw, float* dbias, int nb, hipStream_t st) {
+    long long g = (nw + nb + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_wgrad_slab_reduce, dim3((unsigned)g), dim3(256), 0, st, ws, nslab, stride, dw, nw, dbias, nb);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
 }
 
 extern "C" int rho_conv_wgrad_variant(const rho_conv_desc* dp, int64_t dy_width, char* buf, int cap) {
@@ -872,7 +940,8 @@ extern "C" int rho_conv_wgrad_variant(const rho_conv_desc* dp, int64_t dy_width,
     return rc;
 }
 
-static int wgrad_impl(const rho_conv_desc* dp, const void* dy, int64_t dy_width, float* dw, float* dbias, void* stream) {
+static int wgrad_impl(const rho_conv_desc* dp, const void* dy, int64_t dy_width, float* dw, float* dbias, void* stream, float* ws,
+                      int64_t ws_bytes, int64_t* ws_want) {
     const rho_conv_desc& d = *dp;
     if (!d.x1) return RHO_E_ARG;
     if (d.dtype != RHO_F32 && d.dtype != RHO_BF16) return RHO_E_ARG;
@@ -934,13 +1003,21 @@ static int wgrad_impl(const rho_conv_desc* dp, const void* dy, int64_t dy_width,
         k1.xcd_map = (xcd_env1 && splits % 8 == 0 && (long long)splits * pairs < (1LL << 31)) ? 1 : 0;
         if (cdiv(d.coutp, 64) > 65535 || cdiv(cin, 128) > 65535) return RHO_E_SHAPE;
         dim3 grid((unsigned)splits, (unsigned)cdiv(d.coutp, 64), (unsigned)cdiv(cin, 128));
+        const long long nw1 = (long long)d.coutp * cin;
+        k1.slab_bias_off = nw1; k1.slab_stride = nw1 + d.coutp;
+        if (ws_want) { *ws_want = (int64_t)splits * k1.slab_stride * (int64_t)sizeof(float); return 0; }
         if (g_wvariant != nullptr) {
             snprintf(g_wvariant->buf, (size_t)g_wvariant->cap, "k_wgrad1<bf16>");
             return 0;
         }
+        if (ws) {
+            if (ws_bytes < (int64_t)splits * k1.slab_stride * (int64_t)sizeof(float)) return RHO_E_ARG;
+            k1.slab = ws;
+        }
         hipLaunchKernelGGL(k_wgrad1, grid, dim3(256), (size_t)(4 * 128 * XP + 128 * DYP), as_stream(stream), k1, npos, tiles_total, tpb);
         hipError_t e1 = hipGetLastError();
-        return e1 == hipSuccess ? 0 : (int)e1;
+        if (e1 != hipSuccess) return (int)e1;
+        return ws ? launch_slab_reduce(ws, splits, k1.slab_stride, dw, nw1, dbias, d.coutp, as_stream(stream)) : 0;
     }
     const size_t lds_cap = 160 * 1024;
     int np_cap = (int)((lds_cap - 256 * DYP) / XP);
@@ -992,8 +1069,20 @@ static int wgrad_impl(const rho_conv_desc* dp, const void* dy, int64_t dy_width,
     size_t lds = (size_t)(maxp <= 10 ? 10 : 28) * 64 * XP + 256 * DYP;
     if (maxp <= 10 && !d.pre_a) lds *= 2;     // LDS-DMA path (both dtypes since round 3): double-buffered tiles (2 x 72 KB)
     hipStream_t st = as_stream(stream);
-    if (d.dtype == RHO_BF16) return launch_wgrad_taps<bf16_raw>(d, k, maxp, grid, lds, st);
-    return launch_wgrad_taps<float>(d, k, maxp, grid, lds, st);
+    // deterministic flush: one slab per accumulator owner (the kernel's TAPSPLIT decides whether that is the workgroup or the wave)
+    const int nt = d.kd * d.kh * d.kw;
+    const bool tapsplit = d.dtype == RHO_BF16 ? (nt >= 9) : (nt > 9);
+    const int nslab = splits * (tapsplit ? 1 : 4);
+    const long long nw = (long long)nt * d.coutp * cin;
+    k.slab_bias_off = nw; k.slab_stride = nw + d.coutp;
+    if (ws_want) { *ws_want = (int64_t)nslab * k.slab_stride * (int64_t)sizeof(float); return 0; }
+    if (ws && g_wvariant == nullptr) {
+        if (ws_bytes < (int64_t)nslab * k.slab_stride * (int64_t)sizeof(float)) return RHO_E_ARG;
+        k.slab = ws;
+    }
+    const int rc = d.dtype == RHO_BF16 ? launch_wgrad_taps<bf16_raw>(d, k, maxp, grid, lds, st) : launch_wgrad_taps<float>(d, k, maxp, grid, lds, st);
+    if (rc != 0 || !ws || g_wvariant != nullptr) return rc;
+    return launch_slab_reduce(ws, nslab, k.slab_stride, dw, nw, dbias, d.coutp, st);
 }
 
 // fp32 [taps][coutp][cin_buf] accumulation buffer -> parameter-gradient layout [cout][cin][taps] (fp32),

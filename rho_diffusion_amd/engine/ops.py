@@ -105,10 +105,28 @@ def philox_normal(out: Tensor, seed: int, offset: int = 0, offset_dev: Optional[
 
 def mse(a: Tensor, b: Tensor, want_grad: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
     _f32c(a, "a"), _f32c(b, "b")
-    loss = torch.empty(1, dtype=torch.float32, device=a.device)
+    buf = torch.empty(1 + 1024, dtype=torch.float32, device=a.device)        # loss + the ordered reduction's block partials
+    loss = buf[:1]
     grad = torch.empty_like(a) if want_grad else None
-    check(hip.lib().rho_mse(ptr(a), ptr(b), ptr(loss), ptr(grad), a.numel(), stream()), "rho_mse")
+    check(hip.lib().rho_mse_ws(ptr(a), ptr(b), ptr(loss), ptr(grad), a.numel(), buf.data_ptr() + 4, 1024, stream()), "rho_mse_ws")
     return loss, grad
+
+
+def mean_flat(x: Tensor) -> Tensor:
+    """Mean over all non-batch axes (layers.py:105-110) on the device, float32, fixed summation order."""
+    x = _f32c(x, "x")
+    out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    check(hip.lib().rho_mean_flat(ptr(x), ptr(out), x.shape[0], x.numel() // x.shape[0], stream()), "rho_mean_flat")
+    return out
+
+
+def deterministic() -> bool:
+    """The library's reproducibility switch (RHO_DETERMINISTIC=1 / rho_set_deterministic)."""
+    return bool(hip.lib().rho_get_deterministic())
+
+
+def set_deterministic(on: bool) -> bool:
+    return bool(hip.lib().rho_set_deterministic(1 if on else 0))
 
 
 def adamw(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, beta1: float, beta2: float, eps: float,
@@ -458,6 +476,12 @@ def prep_conv_weight_dgrad(w: Tensor, dtype: torch.dtype, col_src: Optional[Tens
 def conv_wgrad(desc: ConvDesc, dy: Tensor, dw: Tensor, dbias: Optional[Tensor] = None) -> None:
     """Accumulate the weight gradient of the forward conv `desc` into the fp32 buffer dw [taps, coutp, cin] (and, when given,
     the channel sums of dy = the bias gradient into dbias [coutp])."""
+    if deterministic():
+        need = int(hip.lib().rho_conv_wgrad_workspace_bytes(C.byref(desc), dy.shape[-1]))
+        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dy.device)
+        check(hip.lib().rho_conv_nd_wgrad_ws(C.byref(desc), ptr(dy), dy.shape[-1], ptr(dw), ptr(dbias), ptr(ws), need, stream()),
+              "rho_conv_nd_wgrad_ws")
+        return
     check(hip.lib().rho_conv_nd_wgrad(C.byref(desc), ptr(dy), dy.shape[-1], ptr(dw), ptr(dbias), stream()), "rho_conv_nd_wgrad")
 
 

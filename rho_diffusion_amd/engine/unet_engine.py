@@ -388,7 +388,7 @@ class UNetEngine:
             x = x.float()
         x = x.contiguous()
         self.refresh_weights()
-        key = (tuple(x.shape), y is not None, bool(train))
+        key = (tuple(x.shape), y is not None, bool(train)) + self._plan_signature()
         plan = self._plans.get(key)
         if plan is None:
             with torch.inference_mode(False), torch.no_grad():     # plan buffers must stay ordinary tensors
@@ -396,6 +396,24 @@ class UNetEngine:
         if train:
             self._last_train_plan = plan
         return plan.run(x, timesteps, y, t_scalar_dev)
+
+    # environment switches a plan reads while it is built (A/B knobs): part of the plan key, so flipping one rebuilds the plan
+    _PLAN_ENV = ("RHO_TRAIN_MATERIALIZE", "RHO_MATERIALIZE_MIN_COUT", "RHO_PHASE_UPSAMPLE", "RHO_PHASE_UPSAMPLE_BWD", "RHO_PHASE_MIN_WGS",
+                 "RHO_FOLD_SKIP", "RHO_FOLD_SKIP_TRAIN", "RHO_S2_SPLIT", "RHO_S2_SPLIT_BWD", "RHO_FUSE_GN_BWD", "RHO_GEMM_ENDS",
+                 "RHO_DIRECT_ENDS", "RHO_CONV_SPLITK", "RHO_BATCH_PREP", "RHO_DW_ARENA")
+
+    def _plan_signature(self) -> tuple:
+        """Everything besides (shape, labels, mode) that is baked into a plan when it is built: the per-ResBlock ``use_checkpoint``
+        flags (layers.py:153-199 semantics, honoured per block), the library's deterministic switch and the A/B environment knobs.
+        A change of any of them selects (builds) another plan instead of silently replaying the old one."""
+        ck = tuple(bool(b.use_checkpoint) for b in self._film_blocks)
+        env = tuple(os.environ.get(k) for k in self._PLAN_ENV)
+        return (ck, ops.deterministic(), env)
+
+    def drop_plans(self, train_only: bool = False) -> None:
+        """Release cached plans (and their device buffers): all of them, or only the training plans."""
+        self._plans = {k: v for k, v in self._plans.items() if train_only and not k[2]}
+        self._last_train_plan = None
 
     def backward(self, dpred: Tensor, on_ready: Optional[Callable[[List[nn.Parameter]], None]] = None) -> None:
         """Backward of the most recent ``forward(train=True)``: accumulates into ``p.grad`` of every
@@ -884,6 +902,18 @@ class _Plan:
         def pgrad(p: nn.Parameter) -> int:
             return p.grad.data_ptr()       # resolved at launch time: optimizers may re-home .grad
 
+        # Deterministic training (rho_set_deterministic / RHO_DETERMINISTIC=1): the weight gradient flushes through ordered slabs
+        # (rho_conv_nd_wgrad_ws) instead of fp32 atomics; one workspace per plan, sized for its largest launch after all are known
+        self.deterministic = ops.deterministic()
+        det_ws: Dict[str, object] = {"bytes": 0, "t": None}
+
+        def wgrad_call(d, dy_ptr: int, w_: int, dw_ptr: Callable[[], int], db_ptr: Callable[[], int]):
+            if not self.deterministic:
+                return lambda s: L.rho_conv_nd_wgrad(C.byref(d), dy_ptr, w_, dw_ptr(), db_ptr(), s)
+            det_ws["bytes"] = max(det_ws["bytes"], int(L.rho_conv_wgrad_workspace_bytes(C.byref(d), w_)))
+            return lambda s: L.rho_conv_nd_wgrad_ws(C.byref(d), dy_ptr, w_, dw_ptr(), db_ptr(), ptr(det_ws["t"]), det_ws["bytes"], s)
+        self._det_ws = det_ws
+
         def bias_and_wgrad(node, dY: Tensor, dyw: int):
             cw = node["cw"]
             N, Do, Ho, Wo = node["out_dims"]
@@ -911,7 +941,7 @@ class _Plan:
                     nwp = kern[0] * kern[1] * kern[2] * cw.coutp * cw.cinp
                     dwv = dwbuf[:nwp]
                     emit(lambda s, t=dwv: (t.zero_(), 0)[1], "memset", nbytes=4.0 * nwp)
-                    emit(lambda s, d=d, dy=ptr(dY), w_=dyw: L.rho_conv_nd_wgrad(C.byref(d), dy, w_, ptr(dwbuf), ptr(c_tmp), s), "wgrad",
+                    emit(wgrad_call(d, ptr(dY), dyw, lambda: ptr(dwbuf), lambda: ptr(c_tmp)), "wgrad",
                          flops=2.0 * N * S * cw.cout * cw.cin * cw.taps / len(cw.wph),
                          nbytes=float(esz) * (x1.numel() + dY.numel() / len(cw.wph)),
                          cin=cw.cin, cout=cw.cout, taps=cw.taps, positions=N * S // len(cw.wph))
@@ -954,7 +984,7 @@ class _Plan:
             dwv = dwbuf[:nw]
             cbv = c_tmp[:max(dyw, cw.coutp)]
             emit(lambda s, t=dwv, t2=cbv: (t.zero_(), t2.zero_(), 0)[2], "memset", nbytes=4.0 * nw)
-            emit(lambda s, d=d, dy=ptr(dY), w_=dyw: L.rho_conv_nd_wgrad(C.byref(d), dy, w_, ptr(dwbuf), ptr(c_tmp), s), "wgrad",
+            emit(wgrad_call(d, ptr(dY), dyw, lambda: ptr(dwbuf), lambda: ptr(c_tmp)), "wgrad",
                  flops=2.0 * N * S * cw.cout * cw.cin * cw.taps, nbytes=float(esz) * (x1.numel() + dY.numel()),
                  cin=cw.cin, cout=cw.cout, taps=cw.taps, positions=N * S)
             emit(lambda s, cw=cw, rs=rs: L.rho_wgrad_finalize(ptr(dwbuf), pgrad(cw.weight), cw.cout, cw.cin, cw.taps, cw.coutp,
@@ -1191,6 +1221,9 @@ class _Plan:
                                         None, B, eng.mc, e, 0, 1, 0, s), "linear_bwd")
         emb_params += [te2.weight, te2.bias, te0.weight, te0.bias]
         self.bwd_marks.append((len(bw), emb_params))
+        if self.deterministic and det_ws["bytes"] > 0:
+            det_ws["t"] = torch.empty((det_ws["bytes"] + 3) // 4, dtype=torch.float32, device=dev)
+            pool.all.append(det_ws["t"])
         self.pool_bytes = sum(t.numel() * t.element_size() for t in pool.all)
 
     def nbytes(self) -> int:

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("RHO_HIP_LIB") or os.path.join(_HERE, "librho_hip.so")
 
 RHO_F32 = 0
 RHO_BF16 = 1
-ABI_VERSION = 6      # == RHO_ABI_VERSION of include/rho_hip.h (tests/test_cabi.py keeps the two equal)
+ABI_VERSION = 7      # == RHO_ABI_VERSION of include/rho_hip.h (tests/test_cabi.py keeps the two equal)
 
 c_void_p, c_int, c_int32, c_int64, c_uint64, c_float, c_double = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
 
@@ -50,6 +50,10 @@ SIGNATURES = {
     "rho_step_advance": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p]),
     "rho_philox_normal": (c_int, [c_void_p, c_int64, c_uint64, c_uint64, c_void_p, c_void_p]),
     "rho_mse": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "rho_mse_ws": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "rho_mean_flat": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "rho_set_deterministic": (c_int, [c_int]),
+    "rho_get_deterministic": (c_int, []),
     "rho_adamw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int32, c_void_p]),
     "rho_timestep_embed": (c_int, [c_void_p] * 11 + [c_int64, c_int64, c_int64, c_void_p]),
     "rho_multi_embed": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
@@ -86,6 +90,8 @@ SIGNATURES = {
     "rho_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     # ---- backward
     "rho_conv_nd_wgrad": (c_int, [C.POINTER(ConvDesc), c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "rho_conv_nd_wgrad_ws": (c_int, [C.POINTER(ConvDesc), c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "rho_conv_wgrad_workspace_bytes": (c_int64, [C.POINTER(ConvDesc), c_int64]),
     "rho_wgrad_finalize": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int, c_void_p]),
     "rho_wgrad_finalize_phase": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int,
                                         c_void_p]),

@@ -85,7 +85,11 @@ def avg_pool_nd(dims, *args, **kwargs):
 
 @registry.register_layer("mean_flat")
 def mean_flat(tensor):
-    """layers.py:105-110."""
+    """layers.py:105-110: mean over all non-batch axes.  On the product path (GPU tensors) this is the HIP reduction
+    rho_mean_flat (float32, fixed order); a host tensor is a host utility call and stays on torch (the engine never calls this)."""
+    if tensor.is_cuda:
+        from .engine import ops
+        return ops.mean_flat(tensor).to(tensor.dtype)
     return tensor.mean(dim=list(range(1, len(tensor.shape))))
 
 
@@ -105,6 +109,7 @@ def checkpoint(func, inputs, params, flag):
     """layers.py:153-168.  The HIP engine decides itself what to keep and what to recompute in
     backward (attention is always recomputed, as the reference does at unet_v2.py:334), so the flag
     only matters for code that calls this helper directly."""
+    # (host-side control flow only: torch's checkpoint re-invokes ``func``, whatever ``func`` launches; no arithmetic of its own)
     if flag:
         from torch.utils.checkpoint import checkpoint as _ckpt
         return _ckpt(func, *inputs, use_reentrant=False)

@@ -85,9 +85,14 @@ class ResBlock(TimestepBlock):
                  activation=nn.SiLU()):
         super().__init__()
         if dropout:
-            raise NotImplementedError("dropout > 0 is not supported by the HIP engine (all shipped configs use 0)")
+            raise NotImplementedError(
+                f"dropout={dropout}: nn.Dropout(p=dropout) in ResBlock.out_layers (reference rho_diffusion/models/unet_v2.py:239) is not "
+                "built in the HIP engine - every shipped configuration (examples/*.json) trains with dropout 0")
         if not isinstance(activation, nn.SiLU):
-            raise NotImplementedError("the HIP engine fuses SiLU; other activations are not supported")
+            raise NotImplementedError(
+                f"activation={type(activation).__name__}: the reference resolves it through the registry (rho_diffusion/models/"
+                "unet_v2.py:518-519, registry.py:162-170); the HIP engine fuses SiLU into its conv loaders and GroupNorm backward and "
+                "has no other activation for UNetv2 (the legacy UNet, models/unet.py, runs ReLU / GELU)")
         self.channels = channels
         self.emb_channels = emb_channels
         self.dropout = dropout

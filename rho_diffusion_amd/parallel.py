@@ -49,6 +49,10 @@ class GradBucketReducer:
         for b, idxs in enumerate(self.buckets):
             for i in idxs:
                 self.bucket_of[i] = b
+        # bucket-close trace (bench.py, N = 1 "ddp_overlap"): when a list, every bucket close appends (bucket, bytes, HIP event
+        # recorded on the launch stream at the point where the bucket's all-reduce would be issued) - also with world == 1,
+        # where nothing is sent.  The measured position of each close inside the backward is the overlap budget of DESIGN section 6.
+        self.trace: Optional[list] = None
         self.reset()
 
     def reset(self) -> None:
@@ -59,7 +63,7 @@ class GradBucketReducer:
 
     # engine callback ------------------------------------------------------------------
     def on_ready(self, params: Sequence[nn.Parameter]) -> None:
-        if self.world == 1:
+        if self.world == 1 and self.trace is None:
             return
         for p in params:
             i = self.index.get(id(p))
@@ -69,7 +73,12 @@ class GradBucketReducer:
             b = self.bucket_of[i]
             self.pending[b] -= 1
             if self.pending[b] == 0:
-                self._launch(b)
+                if self.trace is not None:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record()
+                    self.trace.append((b, sum(self.params[j].numel() * 4 for j in self.buckets[b]), ev))
+                if self.world > 1:
+                    self._launch(b)
 
     def _flat_view(self, idxs: List[int]) -> Optional[torch.Tensor]:
         """One tensor covering the bucket if its gradients are adjacent in memory (optimizer arena)."""

@@ -151,6 +151,32 @@ def test_c5_whole_network_runs_at_128_cubed_conditioned():
     assert e_all < 3e-2 and e_sl < 3e-2, (e_all, e_sl)
 
 
+def test_c5_whole_network_forward_vs_oracle_at_128_cubed():
+    """BASELINE configs[4] against the CPU ORACLE at its real geometry (round 4; the test above compares the two engines with each
+    other): one conditioned forward at [1, 1, 128, 128, 128] - T = 32768 attention at the 16-fold level, 128^3 convolutions at
+    mc = 32, MultiEmbeddings over the DeepGalaxy space (unet_v2.py:365-436,685-732, conditioning.py:31-139,
+    examples/config_deep_galaxy.json).  Exact-f32 engine rel-L2 <= 1e-4, bf16 engine <= 3e-2, both against ``R.unet_forward`` on the
+    same weights, input and label row (about a minute of host time: the oracle's [4, 32768, 32768] attention matrix is 17 GB)."""
+    model = _bench_unet(3, 128, 32, "fp32", True)
+    x = det_normal((1, 1, 128, 128, 128), "r4c5x")
+    t = torch.tensor([377])
+    y = torch.tensor(galaxy_labels(1), dtype=torch.float32)
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    cfg = dict(data_shape=[128, 128, 128], in_channels=1, out_channels=1, model_channels=32, num_res_blocks=2, channel_mult=(1, 2, 4, 8),
+               attention_resolutions=[16, 8], num_heads=4, use_scale_shift_norm=True, dims=3, activation="SiLU", num_classes=25)
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        ref = R.unet_forward(sd, cfg, x, t, y, DEEP_GALAXY_SPACE)
+        p32 = model(x.to(DEV), t.to(DEV), y.to(DEV))
+        e32 = rel_l2(p32, ref)
+        model._engines.clear()
+        torch.cuda.empty_cache()
+        pbf = model.set_compute_dtype("bf16")(x.to(DEV), t.to(DEV), y.to(DEV))
+    ebf = rel_l2(pbf, ref)
+    assert torch.isfinite(p32).all() and torch.isfinite(pbf).all()
+    assert e32 < 1e-4 and ebf < 3e-2, (e32, ebf)
+
+
 def test_c2_whole_network_runs_at_full_size():
     """BASELINE configs[1]: 2-D 128^2, mc 64, fp32 engine, batch 64: one forward; sample 5 of the batch equals the same sample run
     alone bit for bit or to 1e-5 (per-sample GroupNorm / attention: no cross-sample coupling, layers.py:71-74), and the B = 2 head of

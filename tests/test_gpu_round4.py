@@ -1,0 +1,186 @@
+"""-m gpu, round 4: the reproducible-gradient switch (rho_set_deterministic / RHO_DETERMINISTIC=1: weight gradients through ordered
+slabs instead of fp32 atomics, ordered linear / label-embedding backward, ordered MSE reduction), the plan key (use_checkpoint flags
+and A/B switches select another plan instead of silently replaying the old one), and the small ABI-7 additions."""
+import ctypes as C
+
+import pytest
+import torch
+from torch import nn
+
+from helpers import (PARAM_SPACE, UNET_CASES, case_inputs, det_normal, det_state_dict, det_uniform, golden_template, load_golden,
+                     rel_l2)
+from gpu_util import DEV
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def deterministic():
+    from rho_diffusion_amd.engine import ops
+    old = ops.set_deterministic(True)
+    yield
+    ops.set_deterministic(old)
+
+
+def _train_once(case, dtype, steps=2):
+    """`steps` optimizer steps of the DDPM training step on fixed inputs; returns (losses, flat parameters, first-step gradients)."""
+    from rho_diffusion_amd.diffusion import DDPM, LinearSchedule
+    from rho_diffusion_amd.models import MultiEmbeddings, UNet
+    from rho_diffusion_amd.trainer import DPTrainer
+    kw, xshape, ykind = UNET_CASES[case]
+    extra = {}
+    ddpm = DDPM(UNet, dict(kw, compute_dtype=dtype), LinearSchedule(1000, 1e-3, 0.02), nn.MSELoss, opt_kwargs={"lr": 2e-4}, **extra)
+    if ykind == "multi":
+        ddpm.backbone.cond_fn = MultiEmbeddings(parameter_space=PARAM_SPACE, embedding_dim=4 * kw["model_channels"])
+    ddpm.backbone.load_state_dict(det_state_dict(ddpm.backbone.state_dict(), "r4det"))
+    ddpm = ddpm.to(DEV)
+    trainer = DPTrainer(ddpm, device_timesteps=False)
+    _, _, _, y = case_inputs(case)
+    losses, g0 = [], None
+    for step in range(steps):
+        x0 = det_uniform(xshape, f"r4d_x{step}", 0.0, 1.0).to(DEV)
+        eps = det_normal(xshape, f"r4d_e{step}").to(DEV)
+        t = torch.tensor([(97 + 31 * step + 13 * i) % 1000 for i in range(xshape[0])])
+        ddpm.noise = lambda data, e=eps: e
+        ddpm.random_timesteps = lambda bs, tt=t: tt
+        batch = [x0, y.to(DEV)] if y is not None else x0
+        losses.append(float(trainer.step(batch)))
+        if step == 0:
+            g0 = trainer.opt.flat_grads[0].detach().clone()
+    flat = torch.cat([p_.detach().reshape(-1) for p_ in ddpm.backbone.parameters()]).clone()
+    return losses, flat, g0
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+@pytest.mark.parametrize("case", ["tiny3d", "tiny2d_multi"])
+def test_deterministic_training_is_bit_identical_run_to_run(deterministic, case, dtype):
+    """Two fresh runs of two optimizer steps (q_sample, forward, MSE, backward, AdamW) on the same inputs: every loss, every
+    first-step gradient and every parameter after the second step equal BIT FOR BIT.  (The reference's CPU path is deterministic;
+    the default HIP path is not: the weight gradient, the dx of the FiLM / time-embedding linears and the label-embedding
+    backward add partial sums with fp32 atomics.)"""
+    if case not in UNET_CASES:
+        pytest.skip(f"no golden case {case}")
+    a = _train_once(case, dtype)
+    b = _train_once(case, dtype)
+    assert a[0] == b[0], (a[0], b[0])
+    assert torch.equal(a[2], b[2]), float((a[2] - b[2]).abs().max())
+    assert torch.equal(a[1], b[1]), float((a[1] - b[1]).abs().max())
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_deterministic_gradients_equal_the_atomic_path_up_to_summation_order(dtype):
+    """The ordered-slab flush adds the same partial sums as the atomic flush, in a fixed order: per-parameter gradients agree to the
+    fp32 summation noise (1e-5 relative) - so the gradient goldens that pin the atomic path pin this one too."""
+    from rho_diffusion_amd.engine import ops
+    old = ops.set_deterministic(False)
+    try:
+        ref = _train_once("tiny3d", dtype, steps=1)
+        ops.set_deterministic(True)
+        det = _train_once("tiny3d", dtype, steps=1)
+    finally:
+        ops.set_deterministic(old)
+    assert abs(ref[0][0] - det[0][0]) <= 1e-6 * abs(ref[0][0])
+    d = float((ref[2].double() - det[2].double()).norm() / ref[2].double().norm())
+    assert d < 1e-5, d
+
+
+@pytest.mark.parametrize("dtype,kernel,cin,cout,shape", [
+    ("bf16", (3, 3, 3), 64, 64, (2, 8, 16, 16)), ("bf16", (3, 3, 3), 96, 160, (1, 8, 8, 8)), ("bf16", (1, 1, 1), 160, 96, (2, 4, 8, 8)),
+    ("fp32", (1, 3, 3), 48, 64, (3, 1, 16, 16)), ("fp32", (1, 1, 1), 64, 32, (2, 1, 16, 16)), ("bf16", (1, 3, 3), 64, 64, (2, 1, 32, 32))])
+def test_wgrad_ordered_slabs_match_the_atomic_flush_and_repeat_exactly(dtype, kernel, cin, cout, shape):
+    """rho_conv_nd_wgrad_ws against rho_conv_nd_wgrad on single layers (both accumulator ownerships: taps dealt to the waves, and
+    positions dealt to the waves - 2-D / 1-tap / f32 launches; the GEMM-shaped 1x1x1 kernel): same dW and channel sums to the
+    summation order, and the ordered form bit-identical over repeated launches."""
+    from rho_diffusion_amd import hip
+    from rho_diffusion_amd.engine import ops
+    td = torch.bfloat16 if dtype == "bf16" else torch.float32
+    N, D, H, W = shape
+    x = det_normal((N, D, H, W, cin), "r4wx").to(DEV).to(td)
+    dy = det_normal((N, D, H, W, cout), "r4wdy").to(DEV).to(td)
+    w = ops.prep_conv_weight((det_normal((cout, cin) + tuple(kernel), "r4ww") * 0.05).to(DEV), td)
+    bias = torch.zeros(w.shape[1], device=DEV)
+    desc = ops.make_conv_desc(x, None, w, bias, kernel=kernel, cout=cout, split=cout, y=dy, y2=None)
+    taps, coutp, cinp = w.shape
+
+    def run(det):
+        dw = torch.zeros(taps, coutp, cinp, device=DEV)
+        db = torch.zeros(max(coutp, cout), device=DEV)
+        old = ops.set_deterministic(det)
+        try:
+            ops.conv_wgrad(desc, dy, dw, db)
+        finally:
+            ops.set_deterministic(old)
+        torch.cuda.synchronize()
+        return dw, db
+
+    need = int(hip.lib().rho_conv_wgrad_workspace_bytes(C.byref(desc), cout))
+    assert need > 0
+    a_dw, a_db = run(False)
+    d1_dw, d1_db = run(True)
+    d2_dw, d2_db = run(True)
+    assert torch.equal(d1_dw, d2_dw) and torch.equal(d1_db, d2_db)
+    assert rel_l2(d1_dw, a_dw) < 2e-6 and rel_l2(d1_db[:cout], a_db[:cout]) < 2e-6
+    # and against autograd of the stock conv on the same (rounded) operands
+    xr = x.float().permute(0, 4, 1, 2, 3).cpu().requires_grad_(False)
+    wt = torch.zeros(cout, cin, *kernel, requires_grad=True)
+    pad = tuple(k // 2 for k in kernel)
+    yref = torch.nn.functional.conv3d(xr, wt, None, padding=pad)
+    yref.backward(dy.float().permute(0, 4, 1, 2, 3).cpu())
+    ref = wt.grad.reshape(cout, cin, taps).permute(2, 0, 1)              # [taps, cout, cin]
+    tol = 2e-5 if dtype == "fp32" else 1e-4
+    assert rel_l2(d1_dw[:, :cout, :cin].cpu(), ref) < tol
+
+
+def test_mse_ordered_reduction_is_reproducible_and_exact():
+    from rho_diffusion_amd.engine import ops
+    a = det_normal((4, 1, 32, 32, 32), "r4ma").to(DEV)
+    b = det_normal((4, 1, 32, 32, 32), "r4mb").to(DEV)
+    l1, g1 = ops.mse(a, b, want_grad=True)
+    l2, g2 = ops.mse(a, b, want_grad=True)
+    assert torch.equal(l1, l2) and torch.equal(g1, g2)
+    ref = torch.nn.functional.mse_loss(a.double().cpu(), b.double().cpu())
+    assert abs(float(l1) - float(ref)) < 1e-6 * float(ref)
+    assert torch.allclose(g1.cpu(), (2 * (a - b) / a.numel()).cpu(), rtol=1e-6, atol=0)
+
+
+def test_mean_flat_runs_on_the_device():
+    """layers.mean_flat (layers.py:105-110) of a GPU tensor is the HIP reduction rho_mean_flat, not torch arithmetic."""
+    from rho_diffusion_amd import layers
+    x = det_normal((5, 3, 17, 9), "r4mf").to(DEV)
+    out = layers.mean_flat(x)
+    assert out.shape == (5,) and out.is_cuda
+    assert torch.allclose(out.cpu(), x.cpu().double().mean(dim=(1, 2, 3)).float(), rtol=1e-5, atol=1e-7)
+    from rho_diffusion_amd.registry import registry
+    assert registry.get("layers", "mean_flat") is layers.mean_flat
+
+
+def test_plan_key_follows_use_checkpoint_and_switches(monkeypatch):
+    """toggling ``blk.use_checkpoint`` (or an A/B switch) after the first training forward must build another plan, not
+    silently replay the one built with the old flag."""
+    from rho_diffusion_amd.models import UNet
+    kw, xshape, _ = UNET_CASES["tiny3d"]
+    g = load_golden("g4_unet.npz")
+    model = UNet(**dict(kw), compute_dtype="bf16")
+    model.load_state_dict(det_state_dict(golden_template(g, "tiny3d"), "tiny3d"))
+    model = model.to(DEV).train()
+    _, x, t, _ = case_inputs("tiny3d")
+    eng = model.engine()
+    model(x.to(DEV), t.to(DEV)).float().square().mean().backward()
+    p0 = eng._last_train_plan
+    b0 = p0.nbytes()
+    for blk in model.modules():
+        if type(blk).__name__ == "ResBlock":
+            blk.use_checkpoint = True
+    model(x.to(DEV), t.to(DEV)).float().square().mean().backward()
+    p1 = eng._last_train_plan
+    assert p1 is not p0 and p1.nbytes() < b0
+    for blk in model.modules():
+        if type(blk).__name__ == "ResBlock":
+            blk.use_checkpoint = False
+    model(x.to(DEV), t.to(DEV))
+    assert eng._last_train_plan is p0                        # the first plan is still cached under its own key
+    monkeypatch.setenv("RHO_FOLD_SKIP", "0")
+    model(x.to(DEV), t.to(DEV))
+    assert eng._last_train_plan is not p0 and eng._last_train_plan is not p1
+    eng.drop_plans(train_only=True)
+    assert eng._last_train_plan is None and all(not k[2] for k in eng._plans)

@@ -54,6 +54,7 @@ def _run_case(case, dtype):
     target = det_normal(tuple(pred.shape), case + "tgt").to(DEV)
     loss = mse_loss(pred, target)
     loss.backward()
+    model._last_pred, model._last_target = pred.detach(), target
     return g, model, loss
 
 
@@ -86,9 +87,11 @@ def test_unet_backward_bf16_tracks_reference(case, launch_path):
     against the oracle's full gradient vector (the oracle is pinned to the reference by the g4 digests) - and have its norm
     within 5 %; no free outliers.  Parameters whose reference gradient is numerically zero (below 1e-5 of the global gradient
     norm: e.g. the key bias of an attention block, softmax is shift-invariant) are checked by magnitude instead.  A parameter
-    of <= 4 elements (the head bias of a one-channel model: 2 * mean(pred - target), a sum with full cancellation) gets 8 %: the
-    bf16 engine sits at 4.6 % there with the small-grid launches unsplit and at 4.9 - 5.0 % with the k-split's summation order
-    (the fp32 engine is at 5e-7 either way: only the positions of the bf16 roundings move)."""
+    of <= 4 elements (the head bias of a one-channel model) is 2 * mean(pred - target) per channel, a sum with full cancellation:
+    against the ORACLE's value it carries the bf16 error of `pred` itself amplified by the cancellation (4.6 - 5.0 % depending on
+    where the roundings fall), which says nothing about the backward kernels.  It is therefore pinned against the exact value for
+    the engine's OWN prediction, accumulated in float64 - sum over (n, positions) of 2 (pred - target) / numel - to 1e-3, and only
+    loosely (20 %) against the oracle."""
     from oracle import ref_torch as R
     g, model, loss = _run_case(case, torch.bfloat16)
     assert abs(loss.item() - float(g[f"{case}/loss"])) < 5e-2
@@ -111,7 +114,13 @@ def test_unet_backward_bf16_tracks_reference(case, launch_path):
                 bad.append((name, "should be ~0", dn, rn))
             continue
         c = cosine(p.grad, ref)
-        if c < 0.99 or abs(dn - rn) > (0.08 if p.numel() <= 4 else 0.05) * rn:
+        if p.numel() <= 4 and name == "out.2.bias":
+            dpred = 2.0 * (model._last_pred.double() - model._last_target.double().to(model._last_pred.device)) / model._last_pred.numel()
+            own = dpred.sum(dim=[0] + list(range(2, dpred.dim()))).cpu()
+            if float((p.grad.double().cpu() - own).abs().max()) > 1e-3 * float(own.abs().max()) + 1e-9 or abs(dn - rn) > 0.2 * rn:
+                bad.append((name, "head bias vs its own prediction", p.grad.tolist(), own.tolist(), round(dn / rn, 4)))
+            continue
+        if c < 0.99 or abs(dn - rn) > 0.05 * rn:
             bad.append((name, round(c, 4), round(dn / rn, 4)))
     assert n > 20
     assert not bad, bad[:8]

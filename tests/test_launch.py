@@ -91,6 +91,8 @@ def test_bench_gpus_flag_takes_the_launcher_branch(tmp_path):
     """`python bench.py --gpus 2` without a launcher environment must start 2 ranks (each then fails here for lack of a GPU,
     and the parent must report that failure as a non-zero exit instead of printing an n_gpus = 1 line)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    # (on a box WITH GPUs the ranks must still fail, and without running a bench: the devices are hidden from the children)
+    env.update(HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                         "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
