@@ -304,6 +304,28 @@ int rho_stem_conv3d(const float* x, const void* w, const float* bias, void* y, f
 int rho_head_conv3d(const void* x, const float* pre_a, const float* pre_b, int pre_silu, const void* w, const float* bias, float* out,
                     int64_t n, int64_t d, int64_t h, int64_t w_, int64_t c, void* stream);
 
+/* Batched weight preparation (ABI 7): ONE launch writes every prepared layout a model needs after an optimizer step - what the
+ * per-tensor rho_prep_conv_weight / _dgrad / _phase / _sel calls above write, the zero-padded (and, for the qkv projection,
+ * row-gathered) fp32 bias vectors, and plain fp32 copies (the batched FiLM matrix of ResBlock.emb_layers, unet_v2.py:225-232) -
+ * from a table of rho_prep_op in DEVICE memory.  Op j owns launch blocks [blk0, blk0 + nblk) (blk0 ascending, contiguous, op 0 at 0;
+ * n_blocks = their sum); field meanings per kind are those of the per-tensor call of the same name:
+ *   RHO_PREP_FWD   out[kd*kh*kw][d1 = coutp][d2 = cinp], perm = row_src;   RHO_PREP_DGRAD  out[taps][d1 = rowsp][d2 = colsp], perm = col_src;
+ *   RHO_PREP_PHASE ph_h / ph_w / dgrad, d1 x d2 as rho_prep_conv_weight_phase;   RHO_PREP_SEL kh2 / kw2 / sel_h / sel_w / flip_d / dgrad;
+ *   RHO_PREP_VEC   out float32[d1]: out[i] = w[perm ? perm[i] : i] for i < cout (source length cin), 0 beyond.
+ * total = elements of `out`; dtype = RHO_BF16 / RHO_F32 of `out` (VEC: always float32). */
+enum { RHO_PREP_FWD = 0, RHO_PREP_DGRAD = 1, RHO_PREP_PHASE = 2, RHO_PREP_SEL = 3, RHO_PREP_VEC = 4 };
+typedef struct rho_prep_op {
+    const float* w;
+    void* out;
+    const int32_t* perm;
+    int64_t cout, cin, d1, d2, total;
+    int32_t kind, dtype;
+    int32_t kd, kh, kw, kh2, kw2, ph_h, ph_w, sel_h, sel_w, flip_d, dgrad;
+    int32_t blk0, nblk;
+    int32_t pad_;
+} rho_prep_op;
+int rho_prep_batch(const rho_prep_op* ops_dev, int64_t n_ops, int64_t n_blocks, void* stream);
+
 /* Workspace the k-split of `desc` wants (rho_conv_desc.ws), in bytes; 0 when the launch would not be split: kernels with a depth
  * extent (kd = 3: the batch is grid z there), launches with fused output statistics or channel-major outputs, grids of more than
  * 128 workgroups, fewer than 4 input-channel chunks.  Every kd = 1 launch qualifies otherwise - INCLUDING 1x1x1 launches (also the

@@ -1434,6 +1434,12 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
 
     const size_t lds_cap = 160 * 1024;
     const int taps = d.kd * d.kh * d.kw;
+    {
+        // A/B knob: short contractions (<= N input-channel chunks) on the 4-wave 64-cout tile, two workgroups per CU, instead of the
+        // 8-wave 128-cout tile whose waves all sit in set-up / epilogue at the same time (0 = off)
+        static const int bm64_chunks = getenv("RHO_BM64_MAX_CHUNKS") ? atoi(getenv("RHO_BM64_MAX_CHUNKS")) : 0;
+        if (BM == 128 && bm64_chunks > 0 && d.kd == 3 && taps > 1 && cin / CK <= bm64_chunks) BM = 64;
+    }
     const bool m16 = d.dtype == RHO_BF16 && taps > 1 && taps % 3 == 0 && d.sh == 1 && d.sw == 1 && !d.up_h && !d.up_w;
     const int WSLOTS = (taps % 3 == 0) ? ((((BM == 128 && m16) || (RHO_GB_BM32 && BM == 32)) && RHO_GB_WIDE == 3 && taps % 9 == 0) ? 9 : 3) : 2;   // LDS weight-ring depth (matches the kernel's PIPE / RS)
     int np_cap = (int)((lds_cap - (size_t)WSLOTS * BM * PITCH) / PITCH);

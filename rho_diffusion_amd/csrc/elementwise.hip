@@ -709,6 +709,69 @@ extern "C" int rho_prep_conv_weight_dgrad(const float* w, void* out, int dtype, 
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ batched weight preparation
+// rho_prep_batch: every prepared layout of every convolution of a model (forward / data-gradient / sub-pixel phase / parity
+// selection), the padded fp32 biases and the batched FiLM matrix in ONE launch after an optimizer step, driven by a device table of
+// rho_prep_op.  The per-tensor entry points above cost ~170 launches of a few microseconds per training step at BASELINE
+// configs[2] (2.7 ms) and as many again on the launch-bound 2-D configurations.  A block finds its op by bisection on blk0.
+__device__ __forceinline__ float prep_elem(const rho_prep_op& o, int64_t i) {
+    const int64_t taps = (int64_t)o.kd * o.kh * o.kw;
+    switch (o.kind) {
+    case RHO_PREP_FWD: {                       // [taps][coutp = d1][cinp = d2]
+        const int64_t ci = i % o.d2, co = (i / o.d2) % o.d1, tap = i / (o.d2 * o.d1);
+        const int64_t src = o.perm ? (int64_t)o.perm[co] : (co < o.cout ? co : -1);
+        return (src >= 0 && src < o.cout && ci < o.cin) ? o.w[(src * o.cin + ci) * taps + tap] : 0.0f;
+    }
+    case RHO_PREP_DGRAD: {                     // [taps'][rowsp = d1][colsp = d2], flipped taps, transposed channels
+        const int64_t col = i % o.d2, row = (i / o.d2) % o.d1, tap = i / (o.d2 * o.d1);
+        const int64_t src = o.perm ? (col < o.cout ? (int64_t)o.perm[col] : -1) : (col < o.cout ? col : -1);
+        return (src >= 0 && src < o.cout && row < o.cin) ? o.w[(src * o.cin + row) * taps + (taps - 1 - tap)] : 0.0f;
+    }
+    case RHO_PREP_PHASE: {
+        const int64_t taps2 = (int64_t)o.kd * (o.ph_h ? 2 : o.kh) * (o.ph_w ? 2 : o.kw);
+        const int64_t i2 = i % o.d2, i1 = (i / o.d2) % o.d1;
+        const int tap = (int)(i / (o.d2 * o.d1));
+        if (!o.dgrad) return (i1 < o.cout && i2 < o.cin) ? phase_weight(o.w, i1, i2, o.cin, tap, o.kd, o.kh, o.kw, o.ph_h, o.ph_w) : 0.0f;
+        return (i2 < o.cout && i1 < o.cin) ? phase_weight(o.w, i2, i1, o.cin, (int)(taps2 - 1 - tap), o.kd, o.kh, o.kw, o.ph_h, o.ph_w) : 0.0f;
+    }
+    case RHO_PREP_SEL: {
+        const int64_t i2 = i % o.d2, i1 = (i / o.d2) % o.d1;
+        const int tap = (int)(i / (o.d2 * o.d1));
+        const int c2 = tap % o.kw2, r2 = (tap / o.kw2) % o.kh2, dz = tap / (o.kw2 * o.kh2);
+        const int ks = ((o.flip_d ? o.kd - 1 - dz : dz) * o.kh + ((o.sel_h >> (4 * r2)) & 15)) * o.kw + ((o.sel_w >> (4 * c2)) & 15);
+        const int64_t co = o.dgrad ? i2 : i1, ci = o.dgrad ? i1 : i2;
+        return (co < o.cout && ci < o.cin) ? o.w[(co * o.cin + ci) * taps + ks] : 0.0f;
+    }
+    default: {                                 // RHO_PREP_VEC: out[i] = w[perm ? perm[i] : i] for i < cout, zero up to d1 (fp32 copy / gather)
+        const int64_t src = (o.perm && i < o.cout) ? (int64_t)o.perm[i] : i;
+        return (i < o.cout && src >= 0 && src < o.cin) ? o.w[src] : 0.0f;
+    }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_prep_batch(const rho_prep_op* __restrict__ ops, int nops) {
+    int lo = 0, hi = nops - 1;
+    const int b = (int)blockIdx.x;
+    while (lo < hi) {                          // last op whose first block is <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (ops[mid].blk0 <= b) lo = mid; else hi = mid - 1;
+    }
+    const rho_prep_op o = ops[lo];
+    const int64_t stride = (int64_t)o.nblk * 256;
+    for (int64_t i = (int64_t)(b - o.blk0) * 256 + threadIdx.x; i < o.total; i += stride) {
+        const float v = prep_elem(o, i);
+        if (o.dtype == RHO_BF16 && o.kind != RHO_PREP_VEC) reinterpret_cast<bf16_raw*>(o.out)[i] = f32_to_bf16(v);
+        else reinterpret_cast<float*>(o.out)[i] = v;
+    }
+}
+
+extern "C" int rho_prep_batch(const rho_prep_op* ops_dev, int64_t n_ops, int64_t n_blocks, void* stream) {
+    if (!ops_dev || n_ops <= 0 || n_blocks <= 0 || n_blocks > 0x7FFFFFFF || n_ops > 0x7FFFFFFF) return RHO_E_ARG;
+    hipLaunchKernelGGL(k_prep_batch, dim3((unsigned)n_blocks), dim3(256), 0, as_stream(stream), ops_dev, (int)n_ops);
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
 // nearest x2 on H and/or W of a channels-last tensor, 16-byte pieces (materialised only for the wgrad of Upsample.conv)
 __global__ __launch_bounds__(256) void k_upsample2x(const uint4* __restrict__ x, uint4* __restrict__ y, int64_t nd, int h, int w,
                                                     int cpieces, int uh, int uw) {

@@ -1049,12 +1049,14 @@ static int wgrad_impl(const rho_conv_desc* dp, const void* dy, int64_t dy_width,
     static const int n_cu = []() { hipDeviceProp_t pr; int dev = 0; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
     int splits = cdiv(4 * n_cu, pairs);
     double best = -1.0;
-    for (int r = 3; r <= 6; ++r) {
+    static const int r_lo = getenv("RHO_WGRAD_ROUNDS_MIN") ? atoi(getenv("RHO_WGRAD_ROUNDS_MIN")) : 3;      // (A/B knobs)
+    static const int r_hi = getenv("RHO_WGRAD_ROUNDS_MAX") ? atoi(getenv("RHO_WGRAD_ROUNDS_MAX")) : 6;
+    for (int r = r_lo; r <= r_hi; ++r) {
         int sp = (r * n_cu) / pairs;
         if (sp >= 8) sp &= ~7;                 // multiples of 8: the slab -> XCD map of the kernel needs whole groups of 8 slabs
         if (sp < 1) continue;
         const long long total = (long long)sp * pairs;
-        const double eff = (double)total / (double)(cdiv((int)total, n_cu) * n_cu) - 0.002 * (r > 4 ? r - 4 : 4 - r);
+        const double eff = (double)total / (double)(cdiv((int)total, n_cu) * n_cu) - 0.002 * (r > 4 ? r - 4 : 4 - r) * (r_lo == 3 && r_hi == 6 ? 1.0 : 0.0);
         if (eff > best) { best = eff; splits = sp; }
     }
     if (splits < 1) splits = 1;

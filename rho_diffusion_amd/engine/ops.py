@@ -283,6 +283,73 @@ def prep_conv_weight_sel(w: Tensor, dtype: torch.dtype, sel_hw, *, flip_d: bool 
     return out
 
 
+class PrepTable:
+    """Device table of rho_prep_op for rho_prep_batch: every prepared weight layout / padded bias / fp32 copy of a model in one
+    launch.  ``add_*`` mirror the per-tensor prep calls (same arguments, same results); ``launch()`` uploads the table once."""
+
+    def __init__(self, device):
+        self.device = device
+        self.ops: list = []
+        self.keep: list = []
+        self._dev = None
+        self._blocks = 0
+
+    def _push(self, kind, w: Tensor, out: Tensor, *, cout, cin, d1, d2, perm=None, k=(1, 1, 1), kh2=0, kw2=0, ph=(0, 0), sel=(0, 0),
+              flip_d=False, dgrad=False):
+        _f32c(w, "w")
+        op = hip.PrepOp()
+        op.w, op.out, op.perm = w.data_ptr(), out.data_ptr(), (perm.data_ptr() if perm is not None else None)
+        op.cout, op.cin, op.d1, op.d2, op.total = int(cout), int(cin), int(d1), int(d2), int(out.numel())
+        op.kind, op.dtype = kind, (hip.dtype_code(out.dtype) if kind != hip.PREP_VEC else hip.dtype_code(torch.float32))
+        op.kd, op.kh, op.kw, op.kh2, op.kw2 = int(k[0]), int(k[1]), int(k[2]), int(kh2), int(kw2)
+        op.ph_h, op.ph_w, op.sel_h, op.sel_w, op.flip_d, op.dgrad = int(ph[0]), int(ph[1]), int(sel[0]), int(sel[1]), int(flip_d), int(dgrad)
+        nblk = max(1, min((op.total + 255) // 256, 256))
+        op.blk0, op.nblk = self._blocks, nblk
+        self._blocks += nblk
+        self.ops.append(op)
+        self.keep.append((w, out, perm))
+        self._dev = None
+
+    @staticmethod
+    def _k3(w: Tensor):
+        return [1] * (5 - w.dim()) + [int(v) for v in w.shape[2:]] if w.dim() > 2 else [1, 1, 1]
+
+    def add_fwd(self, w: Tensor, out: Tensor, row_src: Optional[Tensor] = None, k=None):
+        """rho_prep_conv_weight: [Cout, Cin, *k] -> out [taps, CoutP, CinP].  ``k`` overrides the kernel extents of ``w``'s shape
+        (a parameter re-read as a GEMM: any (kd, kh, kw) whose product is the tap count of the view)."""
+        k = self._k3(w) if k is None else k
+        self._push(hip.PREP_FWD, w, out, cout=w.shape[0], cin=w.shape[1], d1=out.shape[1], d2=out.shape[2], perm=row_src, k=k)
+
+    def add_dgrad(self, w: Tensor, out: Tensor, col_src: Optional[Tensor] = None):
+        self._push(hip.PREP_DGRAD, w, out, cout=w.shape[0], cin=w.shape[1], d1=out.shape[1], d2=out.shape[2], perm=col_src, k=self._k3(w))
+
+    def add_phase(self, w: Tensor, out: Tensor, phase_hw, dgrad: bool = False):
+        self._push(hip.PREP_PHASE, w, out, cout=w.shape[0], cin=w.shape[1], d1=out.shape[1], d2=out.shape[2], k=self._k3(w), ph=phase_hw,
+                   dgrad=dgrad)
+
+    def add_sel(self, w: Tensor, out: Tensor, sel_hw, flip_d: bool = False, dgrad: bool = False):
+        k = self._k3(w)
+        sh = tuple(range(k[1])) if sel_hw[0] is None else tuple(sel_hw[0])
+        sw = tuple(range(k[2])) if sel_hw[1] is None else tuple(sel_hw[1])
+        code = lambda t: sum(int(v) << (4 * i) for i, v in enumerate(t))      # noqa: E731
+        self._push(hip.PREP_SEL, w, out, cout=w.shape[0], cin=w.shape[1], d1=out.shape[1], d2=out.shape[2], k=k, kh2=len(sh), kw2=len(sw),
+                   sel=(code(sh), code(sw)), flip_d=flip_d, dgrad=dgrad)
+
+    def add_vec(self, src: Tensor, out: Tensor, perm: Optional[Tensor] = None, n: Optional[int] = None):
+        """out[i] = src[perm[i] if perm else i] for i < n (default: all of src), zeros up to out.numel(); float32 both."""
+        _f32c(out, "out")
+        n = src.numel() if n is None else n
+        self._push(hip.PREP_VEC, src, out, cout=n, cin=src.numel(), d1=out.numel(), d2=1, perm=perm)
+
+    def launch(self) -> None:
+        if not self.ops:
+            return
+        if self._dev is None:
+            raw = b"".join(bytes(op) for op in self.ops)
+            self._dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        check(hip.lib().rho_prep_batch(self._dev.data_ptr(), len(self.ops), self._blocks, stream()), "rho_prep_batch")
+
+
 # ----------------------------------------------------------------------------- GroupNorm
 def gn_nblk(s: int) -> int:
     return int(hip.lib().rho_gn_nblk(s))

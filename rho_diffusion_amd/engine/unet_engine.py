@@ -121,6 +121,34 @@ class _ConvW:
                                                    self.wd.shape[1], self.wd.shape[2], ptr(self.row_src), hip.stream()),
               "rho_prep_conv_weight_dgrad")
 
+    # batchable: every layout is a gather out of the parameter's own storage (rho_prep_batch reads the parameter directly)
+    batchable = True
+
+    def layout_signature(self) -> tuple:
+        return (id(self), self.weight.data_ptr(), self.bias_param.data_ptr(), self.wd is not None, self.wph is not None,
+                self.wphd is not None, self.ws2 is not None, self.ws2d is not None, self.weight.is_contiguous())
+
+    def prep_into(self, table: "ops.PrepTable") -> bool:
+        """Append this conv's prepared layouts (what ``refresh`` writes) to a rho_prep_batch table; False if it cannot be batched."""
+        if not self.batchable or not self.weight.is_contiguous() or not self.bias_param.is_contiguous():
+            return False
+        w = self._source()                      # a view of the parameter (reshape of a contiguous tensor)
+        if w.data_ptr() != self.weight.data_ptr():
+            return False
+        table.add_fwd(w, self.w, self.row_src)
+        bsrc = self._bias_source()
+        table.add_vec(bsrc, self.b, perm=self.row_src, n=(self.row_src.numel() if self.row_src is not None else bsrc.numel()))
+        if self.wd is not None:
+            table.add_dgrad(w, self.wd, self.row_src)
+        for lst, dg in ((self.wph, False), (self.wphd, True)):
+            for ph, t in (lst or []):
+                table.add_phase(w, t, ph, dgrad=dg)
+        for (a, b), t in (self.ws2 or []):
+            table.add_sel(w, t, (self.S2_FWD[a], self.S2_FWD[b]))
+        for (a, b), t in (self.ws2d or []):
+            table.add_sel(w, t, (self.S2_BWD[a], self.S2_BWD[b]), flip_d=True, dgrad=True)
+        return True
+
     def refresh(self) -> None:
         ops.prep_conv_weight(self._source(), self.dtype, self.coutp, self.cinp, self.row_src, out=self.w)
         b = self._bias_source()
@@ -163,6 +191,8 @@ class _StemAsGemm(_ConvW):
 class _HeadAsGemm(_ConvW):
     """Head conv with cout == 1 viewed as a 1x1x1 conv cin -> taps (rows = taps, padded to 32 output channels) whose
     result rho_tap_gather_sum folds over the taps; the bias is added there."""
+
+    batchable = False      # its source is a transposed, zero-padded copy of the parameter, not a view
 
     def __init__(self, weight: nn.Parameter, bias: nn.Parameter, dtype):
         self.taps3 = int(weight[0, 0].numel())
@@ -223,6 +253,9 @@ class UNetEngine:
         self._cond_dev = None      # device-side tables of the label embedding (MultiEmbeddings), built on first use
         self._param_version = -1
         self._ptr_sig = None
+        self._prep_table = None
+        self._prep_sig = None
+        self._prep_eager: List[_ConvW] = []
         self._last_train_plan: Optional["_Plan"] = None
         with torch.inference_mode(False):
             self._collect()
@@ -308,6 +341,26 @@ class UNetEngine:
         self._ptr_sig = sig
         v = self._versions()
         if not force and v == self._param_version:
+            return
+        if os.environ.get("RHO_BATCH_PREP", "1") != "0":
+            # ONE launch (rho_prep_batch) re-packs every layout of every conv, the padded biases and the FiLM matrix; the table is
+            # rebuilt when a layout is added (first training plan, phases, parity splits) or parameter storage moves
+            lsig = tuple(cw.layout_signature() for cw in self._convs) + tuple(blk.emb_layers[1].weight.data_ptr() for blk in self._film_blocks)
+            if self._prep_table is None or self._prep_sig != lsig:
+                table = ops.PrepTable(self.device)
+                self._prep_eager = [cw for cw in self._convs if not cw.prep_into(table)]
+                off = 0
+                for blk in self._film_blocks:
+                    lin = blk.emb_layers[1]
+                    n = lin.weight.shape[0]
+                    table.add_vec(lin.weight.detach().reshape(-1), self.film_w[off:off + n].reshape(-1))
+                    table.add_vec(lin.bias.detach(), self.film_b[off:off + n])
+                    off += n
+                self._prep_table, self._prep_sig = table, lsig
+            self._prep_table.launch()
+            for cw in self._prep_eager:
+                cw.refresh()
+            self._param_version = v
             return
         for cw in self._convs:
             cw.refresh()

@@ -41,6 +41,21 @@ class ConvDesc(C.Structure):
     ]
 
 
+class PrepOp(C.Structure):
+    """struct rho_prep_op (include/rho_hip.h): one prepared layout of one tensor in rho_prep_batch's device table."""
+    _fields_ = [
+        ("w", c_void_p), ("out", c_void_p), ("perm", c_void_p),
+        ("cout", c_int64), ("cin", c_int64), ("d1", c_int64), ("d2", c_int64), ("total", c_int64),
+        ("kind", c_int32), ("dtype", c_int32),
+        ("kd", c_int32), ("kh", c_int32), ("kw", c_int32), ("kh2", c_int32), ("kw2", c_int32), ("ph_h", c_int32), ("ph_w", c_int32),
+        ("sel_h", c_int32), ("sel_w", c_int32), ("flip_d", c_int32), ("dgrad", c_int32),
+        ("blk0", c_int32), ("nblk", c_int32), ("pad_", c_int32),
+    ]
+
+
+PREP_FWD, PREP_DGRAD, PREP_PHASE, PREP_SEL, PREP_VEC = 0, 1, 2, 3, 4
+
+
 # name -> (restype, argtypes); every symbol include/rho_hip.h declares
 SIGNATURES = {
     "rho_abi_version": (c_int, []),
@@ -65,6 +80,7 @@ SIGNATURES = {
     "rho_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
     "rho_pack_input": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     "rho_prep_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    "rho_prep_batch": (c_int, [c_void_p, c_int64, c_int64, c_void_p]),
     "rho_prep_conv_weight_sel": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_int64, c_int64, c_int, c_void_p]),
     "rho_prep_conv_weight_phase": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64,

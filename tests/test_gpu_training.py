@@ -90,8 +90,9 @@ def test_unet_backward_bf16_tracks_reference(case, launch_path):
     of <= 4 elements (the head bias of a one-channel model) is 2 * mean(pred - target) per channel, a sum with full cancellation:
     against the ORACLE's value it carries the bf16 error of `pred` itself amplified by the cancellation (4.6 - 5.0 % depending on
     where the roundings fall), which says nothing about the backward kernels.  It is therefore pinned against the exact value for
-    the engine's OWN prediction, accumulated in float64 - sum over (n, positions) of 2 (pred - target) / numel - to 1e-3, and only
-    loosely (20 %) against the oracle."""
+    the engine's OWN prediction, accumulated in float64 - sum over (n, positions) of 2 (pred - target) / numel - to 3 % (the
+    kernel sums the bf16-rounded dY: 2^-9 per element, random sign, against the cancelled total - 1.4 % on the 1-D case with its few
+    hundred positions, 0.1 % on the 3-D ones), and only loosely (20 %) against the oracle."""
     from oracle import ref_torch as R
     g, model, loss = _run_case(case, torch.bfloat16)
     assert abs(loss.item() - float(g[f"{case}/loss"])) < 5e-2
@@ -117,7 +118,7 @@ def test_unet_backward_bf16_tracks_reference(case, launch_path):
         if p.numel() <= 4 and name == "out.2.bias":
             dpred = 2.0 * (model._last_pred.double() - model._last_target.double().to(model._last_pred.device)) / model._last_pred.numel()
             own = dpred.sum(dim=[0] + list(range(2, dpred.dim()))).cpu()
-            if float((p.grad.double().cpu() - own).abs().max()) > 1e-3 * float(own.abs().max()) + 1e-9 or abs(dn - rn) > 0.2 * rn:
+            if float((p.grad.double().cpu() - own).abs().max()) > 3e-2 * float(own.abs().max()) + 1e-9 or abs(dn - rn) > 0.2 * rn:
                 bad.append((name, "head bias vs its own prediction", p.grad.tolist(), own.tolist(), round(dn / rn, 4)))
             continue
         if c < 0.99 or abs(dn - rn) > 0.05 * rn:
