@@ -304,6 +304,25 @@ int rho_stem_conv3d(const float* x, const void* w, const float* bias, void* y, f
 int rho_head_conv3d(const void* x, const float* pre_a, const float* pre_b, int pre_silu, const void* w, const float* bias, float* out,
                     int64_t n, int64_t d, int64_t h, int64_t w_, int64_t c, void* stream);
 
+/* Batched form of rho_wgrad_finalize / rho_wgrad_finalize_phase (ABI 7): a device table of ops, op j on launch blocks
+ * [blk0, blk0 + nblk) (ascending, contiguous from 0).  total = cout * cin * kd * kh * kw (elements of the parameter gradient walked,
+ * in buffer-row order).  kind 0: grad[row_src ? row_src[r] : r][ci][tap] += dw[tap][r][ci] (dw rows coutp, row width cinb; a bias
+ * gradient is cin = kd = kh = kw = cinb = 1 with coutp = the width of the channel-sum vector).  kind 1: all sub-pixel phases of a conv
+ * behind a nearest x2 upsample (up_h / up_w say which axes are phased; the phase buffers lie phase_stride floats apart in the order
+ * of rho_prep_conv_weight_phase's phases) summed into the 3-tap gradient.  kind 2: grad[ci][taps - 1 - r] += dw[r][ci] for r < cout
+ * rows (cout = the tap count kd * kh * kw, `cin` channels, buffer row width cinb): the weight gradient of a one-output-channel conv
+ * computed as a GEMM against the im2col of its output gradient (taps-as-rows, mirrored).  Always accumulates; no two ops of a launch may
+ * share a gradient. */
+typedef struct rho_wfin_op {
+    const float* dw;
+    float* grad;
+    const int32_t* row_src;
+    int64_t cout, cin, coutp, cinb, total, phase_stride;
+    int32_t kind, kd, kh, kw, up_h, up_w;
+    int32_t blk0, nblk;
+} rho_wfin_op;
+int rho_wgrad_finalize_batch(const rho_wfin_op* ops_dev, int64_t n_ops, int64_t n_blocks, void* stream);
+
 /* Batched weight preparation (ABI 7): ONE launch writes every prepared layout a model needs after an optimizer step - what the
  * per-tensor rho_prep_conv_weight / _dgrad / _phase / _sel calls above write, the zero-padded (and, for the qkv projection,
  * row-gathered) fp32 bias vectors, and plain fp32 copies (the batched FiLM matrix of ResBlock.emb_layers, unet_v2.py:225-232) -
@@ -311,8 +330,9 @@ int rho_head_conv3d(const void* x, const float* pre_a, const float* pre_b, int p
  * n_blocks = their sum); field meanings per kind are those of the per-tensor call of the same name:
  *   RHO_PREP_FWD   out[kd*kh*kw][d1 = coutp][d2 = cinp], perm = row_src;   RHO_PREP_DGRAD  out[taps][d1 = rowsp][d2 = colsp], perm = col_src;
  *   RHO_PREP_PHASE ph_h / ph_w / dgrad, d1 x d2 as rho_prep_conv_weight_phase;   RHO_PREP_SEL kh2 / kw2 / sel_h / sel_w / flip_d / dgrad;
- *   RHO_PREP_VEC   out float32[d1]: out[i] = w[perm ? perm[i] : i] for i < cout (source length cin), 0 beyond.
- * total = elements of `out`; dtype = RHO_BF16 / RHO_F32 of `out` (VEC: always float32). */
+ *   RHO_PREP_VEC   out[d1] (a general gather): out[i] = w[perm ? perm[i] : i] for i < cout (source length cin; perm[i] < 0: zero), 0 beyond -
+ *                  the padded bias vectors, plain copies, and layouts no other kind describes (the head conv's taps-as-rows form).
+ * total = elements of `out`; dtype = RHO_BF16 / RHO_F32 of `out`. */
 enum { RHO_PREP_FWD = 0, RHO_PREP_DGRAD = 1, RHO_PREP_PHASE = 2, RHO_PREP_SEL = 3, RHO_PREP_VEC = 4 };
 typedef struct rho_prep_op {
     const float* w;
@@ -416,7 +436,9 @@ int rho_prep_conv_weight_dgrad(const float* w, void* out, int dtype, int64_t cou
  *             dgamma / dbeta (summed over samples, optionally accumulated), FiLM gradients dscale / dshift
  *             ([N, C] at row stride dfilm_stride), and the coefficients cA [N,C], cP / cQ [N,32] of pass 3;
  *             work_nc2 is float32 [2][N][C] scratch
- *   apply   : dx = cA*g*act'(u) + cP + cQ*x, written (or accumulated) into the one or two source gradients. */
+ *   apply   : dx = cA*g*act'(u) + cP + cQ*x, written (or accumulated) into the one or two source gradients.  add1 (ABI 7, may be
+ *             NULL): a further addend of dx1, same shape - the gradient that reaches x1 through a residual connection
+ *             (unet_v2.py:293, :342), folded in here instead of a rho_add_inplace pass of its own. */
 int rho_gn_bwd_reduce(const void* g, const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t n,
                       int64_t s, const float* a, const float* b, const float* stats, int pre_silu, float* partials,
                       void* stream);
@@ -426,7 +448,7 @@ int rho_gn_bwd_finalize(const float* partials, int64_t n, int64_t c, int64_t s, 
                         int64_t dfilm_stride, float* cA, float* cP, float* cQ, void* stream);
 int rho_gn_bwd_apply(const void* g, const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t n,
                      int64_t s, const float* a, const float* b, int pre_silu, const float* cA, const float* cP,
-                     const float* cQ, void* dx1, void* dx2, int acc1, int acc2, void* stream);
+                     const float* cQ, void* dx1, void* dx2, int acc1, int acc2, const void* add1, void* stream);
 
 /* rho_gn_finalize over one or two sources (the virtual concat), each with its own partial-sum format:
  *   fmt 0: rho_gn_partial's layout  [n][nblk][c/8][16]  (8 sums, 8 sums of squares per channel octet)

@@ -742,7 +742,7 @@ __device__ __forceinline__ float prep_elem(const rho_prep_op& o, int64_t i) {
         const int64_t co = o.dgrad ? i2 : i1, ci = o.dgrad ? i1 : i2;
         return (co < o.cout && ci < o.cin) ? o.w[(co * o.cin + ci) * taps + ks] : 0.0f;
     }
-    default: {                                 // RHO_PREP_VEC: out[i] = w[perm ? perm[i] : i] for i < cout, zero up to d1 (fp32 copy / gather)
+    default: {                                 // RHO_PREP_VEC: out[i] = w[perm ? perm[i] : i] for i < cout (perm < 0: zero), zero up to d1
         const int64_t src = (o.perm && i < o.cout) ? (int64_t)o.perm[i] : i;
         return (i < o.cout && src >= 0 && src < o.cin) ? o.w[src] : 0.0f;
     }
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(256) void k_prep_batch(const rho_prep_op* __restric
     const int64_t stride = (int64_t)o.nblk * 256;
     for (int64_t i = (int64_t)(b - o.blk0) * 256 + threadIdx.x; i < o.total; i += stride) {
         const float v = prep_elem(o, i);
-        if (o.dtype == RHO_BF16 && o.kind != RHO_PREP_VEC) reinterpret_cast<bf16_raw*>(o.out)[i] = f32_to_bf16(v);
+        if (o.dtype == RHO_BF16) reinterpret_cast<bf16_raw*>(o.out)[i] = f32_to_bf16(v);
         else reinterpret_cast<float*>(o.out)[i] = v;
     }
 }

@@ -566,13 +566,21 @@ __device__ __forceinline__ void store_octet<float>(float* p, const float (&v)[8]
     *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
 
+// value as the storage type would hold it (bf16: one rounding; f32: itself)
+template <typename T>
+__device__ __forceinline__ float cvt_round(float v);
+template <>
+__device__ __forceinline__ float cvt_round<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ float cvt_round<bf16_raw>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_gn_bwd_apply(const T* __restrict__ g, const T* __restrict__ x1, int c1,
                                                       const T* __restrict__ x2, int c2, int64_t s, int nblk,
                                                       const float* __restrict__ a, const float* __restrict__ b, int pre_silu,
                                                       const float* __restrict__ cA, const float* __restrict__ cP,
                                                       const float* __restrict__ cQ, T* __restrict__ dx1, T* __restrict__ dx2,
-                                                      int acc1, int acc2) {
+                                                      int acc1, int acc2, const T* __restrict__ add1) {
     // same thread -> (channel octet, position lane) map as the reducers: the 5 per-channel coefficients live in
     // registers for the whole position walk (the elementwise form re-loaded them and divided indices per element)
     const int C = c1 + c2;
@@ -592,6 +600,8 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(const T* __restrict__ g, c
     T* dst = first ? dx1 + (int64_t)n * s * c1 + ch : dx2 + (int64_t)n * s * c2 + (ch - c1);
     const int64_t stride = first ? c1 : c2;
     const int accf = first ? acc1 : acc2;
+    // a further addend of dx1 (the gradient arriving through a residual connection: what a separate rho_add_inplace pass added)
+    const T* e1 = (first && add1 != nullptr) ? add1 + (int64_t)n * s * c1 + ch : nullptr;
     const T* gp = g + (int64_t)n * s * C + ch;
     float av[8], bv[8], ca[8], cp[8], cq[8];
 #pragma unroll
@@ -605,13 +615,19 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(const T* __restrict__ g, c
         float xv[8], gv[8], ov[8];
         load_octet<T>(xs + p * stride, xv);
         load_octet<T>(gp + p * C, gv);
+        float ev[8];
         if (accf) load_octet<T>(dst + p * stride, ov);
+        if (e1) load_octet<T>(e1 + p * stride, ev);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float gq = gv[j];
             if (pre_silu) gq *= dsilu_f(fmaf(av[j], xv[j], bv[j]));
             float r = fmaf(ca[j], gq, fmaf(cq[j], xv[j], cp[j]));
-            if (accf) r += ov[j];
+            // (the order of the separate passes: the residual's gradient joins the running sum first, rounded to the storage type as
+            //  rho_add_inplace stores it, then this term)
+            if (accf && e1) r += cvt_round<T>(ov[j] + ev[j]);
+            else if (accf) r += ov[j];
+            else if (e1) r += ev[j];
             ov[j] = r;
         }
         store_octet<T>(dst + p * stride, ov);
@@ -620,7 +636,7 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(const T* __restrict__ g, c
 
 extern "C" int rho_gn_bwd_apply(const void* g, const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t n,
                                 int64_t s, const float* a, const float* b, int pre_silu, const float* cA, const float* cP,
-                                const float* cQ, void* dx1, void* dx2, int acc1, int acc2, void* stream) {
+                                const float* cQ, void* dx1, void* dx2, int acc1, int acc2, const void* add1, void* stream) {
     if (!g || !x1 || !a || !b || !cA || !cP || !cQ || !dx1 || n <= 0 || s <= 0) return RHO_E_ARG;
     if (!x2) c2 = 0;
     if (c2 > 0 && !dx2) return RHO_E_ARG;
@@ -632,10 +648,10 @@ extern "C" int rho_gn_bwd_apply(const void* g, const void* x1, int64_t c1, const
     if (dtype == RHO_BF16)
         hipLaunchKernelGGL(k_gn_bwd_apply<bf16_raw>, grid, block, 0, as_stream(stream), (const bf16_raw*)g, (const bf16_raw*)x1,
                            (int)c1, (const bf16_raw*)x2, (int)c2, s, nblk, a, b, pre_silu, cA, cP, cQ, (bf16_raw*)dx1, (bf16_raw*)dx2,
-                           acc1, acc2);
+                           acc1, acc2, (const bf16_raw*)add1);
     else if (dtype == RHO_F32)
         hipLaunchKernelGGL(k_gn_bwd_apply<float>, grid, block, 0, as_stream(stream), (const float*)g, (const float*)x1, (int)c1,
-                           (const float*)x2, (int)c2, s, nblk, a, b, pre_silu, cA, cP, cQ, (float*)dx1, (float*)dx2, acc1, acc2);
+                           (const float*)x2, (int)c2, s, nblk, a, b, pre_silu, cA, cP, cQ, (float*)dx1, (float*)dx2, acc1, acc2, (const float*)add1);
     else
         return RHO_E_ARG;
     RHO_LAUNCH_CHECK();

@@ -1149,3 +1149,86 @@ extern "C" int rho_wgrad_finalize_phase(const float* dw, float* grad, int64_t co
     RHO_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ batched finalize
+// rho_wgrad_finalize_batch: the [taps][coutp][cin_buf] accumulation buffers of MANY convolutions (and their channel-sum vectors =
+// bias gradients) into the parameter-gradient layout in one launch, from a device table of rho_wfin_op.  The per-tensor calls
+// above are ~170 launches of a few microseconds per training step at BASELINE configs[2] and as many on the launch-bound 2-D
+// configurations.  kind 0 = rho_wgrad_finalize (weights; a bias is the cin = taps = 1 case), kind 1 = ALL sub-pixel phases of one
+// conv behind a nearest x2 upsample (their buffers `phase_stride` floats apart, in the order (a, b) for a in H phases for b in W
+// phases) summed into the 3-tap parameter gradient - one op, so no two ops of a launch touch the same gradient element.
+__device__ __forceinline__ void wfin_elem(const rho_wfin_op& o, int64_t i) {
+    const int64_t taps = (int64_t)o.kd * o.kh * o.kw;
+    const int tap = (int)(i % taps);
+    const int64_t ci = (i / taps) % o.cin;
+    const int64_t r = i / (taps * o.cin);
+    if (o.kind == 2) {          // i walks [ci][tap]: grad[ci][tap] += dw[taps - 1 - tap][ci]
+        const int64_t cc = i / taps;
+        if (cc < o.cin) o.grad[i] += o.dw[(int64_t)(taps - 1 - tap) * o.cinb + cc];
+        return;
+    }
+    if (o.kind == 0) {
+        const int64_t dst_row = o.row_src ? (int64_t)o.row_src[r] : r;
+        if (dst_row < 0 || dst_row >= o.cout) return;
+        float* g = o.grad + (dst_row * o.cin + ci) * taps + tap;
+        *g += o.dw[((int64_t)tap * o.coutp + r) * o.cinb + ci];
+        return;
+    }
+    const int kx = tap % o.kw, ky = (tap / o.kw) % o.kh, kz = tap / (o.kw * o.kh);
+    const int kh2 = o.up_h ? 2 : o.kh, kw2 = o.up_w ? 2 : o.kw;
+    const int nb = o.up_w ? 2 : 1;
+    float v = 0.0f;
+    for (int a = (o.up_h ? 1 : 0); a <= (o.up_h ? 2 : 0); ++a)
+        for (int b = (o.up_w ? 1 : 0); b <= (o.up_w ? 2 : 0); ++b) {
+            const int r2 = a == 0 ? ky : a == 1 ? (ky == 0 ? 0 : 1) : (ky == 2 ? 1 : 0);
+            const int c2 = b == 0 ? kx : b == 1 ? (kx == 0 ? 0 : 1) : (kx == 2 ? 1 : 0);
+            const int pidx = (o.up_h ? a - 1 : 0) * nb + (o.up_w ? b - 1 : 0);
+            v += o.dw[(int64_t)pidx * o.phase_stride + ((int64_t)((kz * kh2 + r2) * kw2 + c2) * o.coutp + r) * o.cinb + ci];
+        }
+    o.grad[i] += v;
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_finalize_batch(const rho_wfin_op* __restrict__ ops, int nops) {
+    __shared__ float tile[32 * 65];            // [tap][64 channels] (+1: conflict-free column reads)
+    int lo = 0, hi = nops - 1;
+    const int b = (int)blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (ops[mid].blk0 <= b) lo = mid; else hi = mid - 1;
+    }
+    const rho_wfin_op o = ops[lo];
+    const int taps = o.kd * o.kh * o.kw;
+    if (o.kind == 0 && taps > 1 && taps <= 32) {
+        // [tap][row][channel] -> [row][channel][tap] through LDS: the buffer is read in 256-byte channel runs (one per tap), the
+        // gradient written as one contiguous run of 64 * taps floats - both sides coalesced (the elementwise walk reads the buffer
+        // with a stride of coutp * cin_buf floats between consecutive threads)
+        const int64_t cg = (o.cin + 63) / 64;                      // 64-channel groups per row
+        const int64_t units = o.cout * cg;
+        for (int64_t u = b - o.blk0; u < units; u += o.nblk) {
+            const int64_t r = u / cg;
+            const int ci0 = (int)(u % cg) * 64;
+            const int nc = (int)min((int64_t)64, o.cin - ci0);
+            for (int e = threadIdx.x; e < taps * 64; e += 256) {
+                const int t = e >> 6, c = e & 63;
+                tile[t * 65 + c] = c < nc ? o.dw[((int64_t)t * o.coutp + r) * o.cinb + ci0 + c] : 0.0f;
+            }
+            __syncthreads();
+            const int64_t dst_row = o.row_src ? (int64_t)o.row_src[r] : r;
+            if (dst_row >= 0 && dst_row < o.cout) {
+                float* g = o.grad + (dst_row * o.cin + ci0) * taps;
+                for (int e = threadIdx.x; e < nc * taps; e += 256) g[e] += tile[(e % taps) * 65 + e / taps];
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    const int64_t stride = (int64_t)o.nblk * 256;
+    for (int64_t i = (int64_t)(b - o.blk0) * 256 + threadIdx.x; i < o.total; i += stride) wfin_elem(o, i);
+}
+
+extern "C" int rho_wgrad_finalize_batch(const rho_wfin_op* ops_dev, int64_t n_ops, int64_t n_blocks, void* stream) {
+    if (!ops_dev || n_ops <= 0 || n_blocks <= 0 || n_blocks > 0x7FFFFFFF || n_ops > 0x7FFFFFFF) return RHO_E_ARG;
+    hipLaunchKernelGGL(k_wgrad_finalize_batch, dim3((unsigned)n_blocks), dim3(256), 0, as_stream(stream), ops_dev, (int)n_ops);
+    RHO_LAUNCH_CHECK();
+    return 0;
+}

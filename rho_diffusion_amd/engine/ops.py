@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -300,10 +301,10 @@ class PrepTable:
         op = hip.PrepOp()
         op.w, op.out, op.perm = w.data_ptr(), out.data_ptr(), (perm.data_ptr() if perm is not None else None)
         op.cout, op.cin, op.d1, op.d2, op.total = int(cout), int(cin), int(d1), int(d2), int(out.numel())
-        op.kind, op.dtype = kind, (hip.dtype_code(out.dtype) if kind != hip.PREP_VEC else hip.dtype_code(torch.float32))
+        op.kind, op.dtype = kind, hip.dtype_code(out.dtype)
         op.kd, op.kh, op.kw, op.kh2, op.kw2 = int(k[0]), int(k[1]), int(k[2]), int(kh2), int(kw2)
         op.ph_h, op.ph_w, op.sel_h, op.sel_w, op.flip_d, op.dgrad = int(ph[0]), int(ph[1]), int(sel[0]), int(sel[1]), int(flip_d), int(dgrad)
-        nblk = max(1, min((op.total + 255) // 256, 256))
+        nblk = max(1, min((op.total + 1023) // 1024, int(os.environ.get("RHO_PREP_MAX_BLOCKS", "2048"))))
         op.blk0, op.nblk = self._blocks, nblk
         self._blocks += nblk
         self.ops.append(op)
@@ -336,8 +337,10 @@ class PrepTable:
                    sel=(code(sh), code(sw)), flip_d=flip_d, dgrad=dgrad)
 
     def add_vec(self, src: Tensor, out: Tensor, perm: Optional[Tensor] = None, n: Optional[int] = None):
-        """out[i] = src[perm[i] if perm else i] for i < n (default: all of src), zeros up to out.numel(); float32 both."""
-        _f32c(out, "out")
+        """out.flat[i] = src.flat[perm[i] if perm else i] for i < n (default: all of src; perm[i] < 0: zero), zeros up to out.numel();
+        src float32, out float32 or bf16 - a general gather (padded biases, plain copies, layouts no other kind describes)."""
+        if not out.is_contiguous():
+            raise RhoHipError("add_vec: out must be contiguous")
         n = src.numel() if n is None else n
         self._push(hip.PREP_VEC, src, out, cout=n, cin=src.numel(), d1=out.numel(), d2=1, perm=perm)
 
@@ -561,8 +564,9 @@ def wgrad_finalize(dw: Tensor, grad: Tensor, row_src: Optional[Tensor] = None, a
 
 def gn_bwd(g: Tensor, x1: Tensor, x2: Optional[Tensor], a: Tensor, b: Tensor, stats: Tensor, gamma: Tensor, beta: Tensor,
            pre_silu: bool, dx1: Tensor, dx2: Optional[Tensor], dgamma: Tensor, dbeta: Tensor, *, scale=None, film_stride=0,
-           dscale=None, dshift=None, dfilm_stride=0, acc_params=False, acc1=False, acc2=False, ws=None):
-    """Backward of act(GN(x)*(1+scale)+shift); scale/dscale/dshift may be raw pointers (ints) or tensors."""
+           dscale=None, dshift=None, dfilm_stride=0, acc_params=False, acc1=False, acc2=False, ws=None, add1: Optional[Tensor] = None):
+    """Backward of act(GN(x)*(1+scale)+shift); scale/dscale/dshift may be raw pointers (ints) or tensors.  ``add1``: a further
+    addend of dx1 (a residual connection's gradient) folded into the apply pass."""
     N = x1.shape[0]
     c1 = x1.shape[-1]
     c2 = x2.shape[-1] if x2 is not None else 0
@@ -584,7 +588,7 @@ def gn_bwd(g: Tensor, x1: Tensor, x2: Optional[Tensor], a: Tensor, b: Tensor, st
                                 ptr(ws["work"]), ptr(dgamma), ptr(dbeta), int(acc_params), p(dscale), p(dshift), dfilm_stride,
                                 ptr(ws["cA"]), ptr(ws["cP"]), ptr(ws["cQ"]), stream()), "rho_gn_bwd_finalize")
     check(L.rho_gn_bwd_apply(ptr(g), ptr(x1), c1, ptr(x2), c2, dt, N, S, ptr(a), ptr(b), int(pre_silu), ptr(ws["cA"]), ptr(ws["cP"]),
-                             ptr(ws["cQ"]), ptr(dx1), ptr(dx2), int(acc1), int(acc2), stream()), "rho_gn_bwd_apply")
+                             ptr(ws["cQ"]), ptr(dx1), ptr(dx2), int(acc1), int(acc2), ptr(add1), stream()), "rho_gn_bwd_apply")
 
 
 def chan_sum(x: Tensor, out_nc: Tensor, out_c: Optional[Tensor] = None, nc_stride: int = 0, acc_nc=False, acc_c=False,

@@ -192,7 +192,53 @@ class _HeadAsGemm(_ConvW):
     """Head conv with cout == 1 viewed as a 1x1x1 conv cin -> taps (rows = taps, padded to 32 output channels) whose
     result rho_tap_gather_sum folds over the taps; the bias is added there."""
 
-    batchable = False      # its source is a transposed, zero-padded copy of the parameter, not a view
+    # its source is a transposed, zero-padded copy of the parameter, not a view: batched as a gather (RHO_PREP_VEC) through an
+    # index table built once - w[0][r = tap][c] = weight[0][c][r]
+    def prep_into(self, table: "ops.PrepTable") -> bool:
+        if not self.weight.is_contiguous():
+            return False
+        if getattr(self, "_perm", None) is None:
+            r = torch.arange(self.w.shape[1]).view(-1, 1)
+            c = torch.arange(self.w.shape[2]).view(1, -1)
+            idx = torch.where((r < self.taps3) & (c < self.cin), c * self.taps3 + r, torch.full_like(r + c, -1))
+            self._perm = idx.reshape(-1).to(torch.int32).to(self.w.device)
+        table.add_vec(self.weight.detach().reshape(-1), self.w, perm=self._perm, n=self.w.numel())
+        return True                                  # (b stays zero: the bias is added by the kernel that folds the taps)
+
+
+class _HeadDgradW:
+    """Data-gradient weights of a one-output-channel 3x3x3 head conv in the layout rho_stem_conv3d reads ([1][C][32], taps as the
+    contraction): dact[pos][c] = sum_tap W[0][c][tap] dpred[pos - (tap - 1)] is that kernel run on dpred with the taps mirrored,
+    w[0][c][t] = weight[0][c][26 - t]  (training plans of the bf16 engine, round 4)."""
+
+    batchable = True
+
+    def __init__(self, weight: nn.Parameter, dtype):
+        self.weight = weight
+        C_ = weight.shape[1]
+        self.taps3 = int(weight[0, 0].numel())
+        dev = weight.device
+        self.w = torch.zeros(1, C_, 32, dtype=dtype, device=dev)
+        self.zero_bias = torch.zeros(C_, dtype=torch.float32, device=dev)
+        c = torch.arange(C_).view(-1, 1)
+        t = torch.arange(32).view(1, -1)
+        idx = torch.where(t < self.taps3, c * self.taps3 + (self.taps3 - 1 - t), torch.full_like(c + t, -1))
+        self._perm = idx.reshape(-1).to(torch.int32).to(dev)
+        self.refresh()
+
+    def layout_signature(self) -> tuple:
+        return (id(self), self.weight.data_ptr())
+
+    def prep_into(self, table: "ops.PrepTable") -> bool:
+        if not self.weight.is_contiguous():
+            return False
+        table.add_vec(self.weight.detach().reshape(-1), self.w, perm=self._perm, n=self.w.numel())
+        return True
+
+    def refresh(self) -> None:
+        src = self.weight.detach().reshape(-1).float()
+        g = torch.where(self._perm >= 0, src[self._perm.clamp(min=0).long()], torch.zeros((), device=src.device))   # (data movement only)
+        self.w.copy_(g.view_as(self.w))
 
     def __init__(self, weight: nn.Parameter, bias: nn.Parameter, dtype):
         self.taps3 = int(weight[0, 0].numel())
@@ -247,6 +293,7 @@ class UNetEngine:
         self.ssn = bool(model.use_scale_shift_norm)
         self._plans: Dict[tuple, "_Plan"] = {}
         self._convs: List[_ConvW] = []
+        self._aux_weights: list = []          # prepared layouts that are not convolutions of their own (see _head_dgrad)
         self._conv_of: Dict[int, _ConvW] = {}
         self._film_blocks: List[nn.Module] = []
         self._omega: Optional[Tensor] = None
@@ -277,6 +324,15 @@ class UNetEngine:
             cw = cls(mod.weight, mod.bias, self.dtype)
             self._conv_of[key] = cw
             self._convs.append(cw)
+        return self._conv_of[key]
+
+    def _head_dgrad(self, mod: nn.Module) -> "_HeadDgradW":
+        """Mirrored taps-as-contraction weights of the one-channel head conv (training plans: its data gradient runs on rho_stem_conv3d)."""
+        key = (id(mod), "_HeadDgradW")
+        if key not in self._conv_of:
+            hw = _HeadDgradW(mod.weight, self.dtype)
+            self._conv_of[key] = hw
+            self._aux_weights.append(hw)
         return self._conv_of[key]
 
     def _qkv_row_src(self, blk) -> Tensor:
@@ -345,10 +401,11 @@ class UNetEngine:
         if os.environ.get("RHO_BATCH_PREP", "1") != "0":
             # ONE launch (rho_prep_batch) re-packs every layout of every conv, the padded biases and the FiLM matrix; the table is
             # rebuilt when a layout is added (first training plan, phases, parity splits) or parameter storage moves
-            lsig = tuple(cw.layout_signature() for cw in self._convs) + tuple(blk.emb_layers[1].weight.data_ptr() for blk in self._film_blocks)
+            allw = self._convs + self._aux_weights
+            lsig = tuple(cw.layout_signature() for cw in allw) + tuple(blk.emb_layers[1].weight.data_ptr() for blk in self._film_blocks)
             if self._prep_table is None or self._prep_sig != lsig:
                 table = ops.PrepTable(self.device)
-                self._prep_eager = [cw for cw in self._convs if not cw.prep_into(table)]
+                self._prep_eager = [cw for cw in allw if not cw.prep_into(table)]
                 off = 0
                 for blk in self._film_blocks:
                     lin = blk.emb_layers[1]
@@ -362,7 +419,7 @@ class UNetEngine:
                 cw.refresh()
             self._param_version = v
             return
-        for cw in self._convs:
+        for cw in self._convs + self._aux_weights:
             cw.refresh()
         off = 0
         for blk in self._film_blocks:
@@ -453,7 +510,7 @@ class UNetEngine:
     # environment switches a plan reads while it is built (A/B knobs): part of the plan key, so flipping one rebuilds the plan
     _PLAN_ENV = ("RHO_TRAIN_MATERIALIZE", "RHO_MATERIALIZE_MIN_COUT", "RHO_PHASE_UPSAMPLE", "RHO_PHASE_UPSAMPLE_BWD", "RHO_PHASE_MIN_WGS",
                  "RHO_FOLD_SKIP", "RHO_FOLD_SKIP_TRAIN", "RHO_S2_SPLIT", "RHO_S2_SPLIT_BWD", "RHO_FUSE_GN_BWD", "RHO_GEMM_ENDS",
-                 "RHO_DIRECT_ENDS", "RHO_CONV_SPLITK", "RHO_BATCH_PREP", "RHO_DW_ARENA")
+                 "RHO_DIRECT_ENDS", "RHO_CONV_SPLITK", "RHO_BATCH_PREP", "RHO_DW_ARENA", "RHO_FOLD_ADD", "RHO_FIN_BATCH_MB")
 
     def _plan_signature(self) -> tuple:
         """Everything besides (shape, labels, mode) that is baked into a plan when it is built: the per-ResBlock ``use_checkpoint``
@@ -842,8 +899,13 @@ class _Plan:
         # 3-D, one input / output channel: each end is ONE launch with its intermediate in LDS (csrc/ends.hip; A/B switch) instead
         # of the GEMM form's two (im2col + GEMM, GEMM + tap gather)
         direct_ends = gemm_ends and dims == 3 and os.environ.get("RHO_DIRECT_ENDS", "1") != "0"
+        # training plans (round 4): the same two forward launches; their backward = GEMM-shaped weight gradients against an im2col
+        # of the one-channel operand (k_wgrad1) and, for the head's data gradient, rho_stem_conv3d on dpred with mirrored taps -
+        # instead of 3x3x3 launches whose single channel is padded to 32 (31 / 32 of their matrix work on zeros)
+        direct_ends_train = (train and dt == torch.bfloat16 and dims == 3 and os.environ.get("RHO_DIRECT_ENDS", "1") != "0"
+                             and os.environ.get("RHO_DIRECT_ENDS_TRAIN", "1") != "0" and os.environ.get("RHO_DW_ARENA", "1") != "0")
         stem_direct = None
-        if direct_ends and xshape[1] == 1 and tuple(stem.kernel) == (3, 3, 3) and stem.cout in (32, 64):
+        if (direct_ends or direct_ends_train) and xshape[1] == 1 and tuple(stem.kernel) == (3, 3, 3) and stem.cout in (32, 64):
             sg = eng._conv_as_gemm(m.input_blocks[0][0], _StemAsGemm)
 
             def stem_direct():
@@ -855,6 +917,8 @@ class _Plan:
                 self.tstats[y.data_ptr()] = (sbuf, tiles)
                 npos = B * D * H * W
                 self.info.append(dict(kind="stem", flops=2.0 * npos * sg.cout * 27, bytes=4.0 * npos + float(esz) * npos * sg.cout))
+                if train:
+                    self.nodes.append(dict(k="stem_direct", y=y, cw=stem, out_dims=(B, D, H, W)))
                 return y
             self.x_cl = self.x_in
         elif gemm_ends and stem.taps > 1 and stem.cin * stem.taps <= 32:
@@ -879,13 +943,23 @@ class _Plan:
             h = run_block(blk, h, hs.pop())
         g = gn(h, None, m.out[0])
         head = eng._conv(m.out[2])
-        if direct_ends and tuple(head.kernel) == (3, 3, 3) and head.cout == 1 and h.shape[-1] in (32, 64, 96, 128):
+        if ((direct_ends or direct_ends_train) and tuple(head.kernel) == (3, 3, 3) and head.cout == 1
+                and h.shape[-1] in ((32, 64) if train else (32, 64, 96, 128))):      # (training: dpred -> dact runs on rho_stem_conv3d)
             hg = eng._conv_as_gemm(m.out[2], _HeadAsGemm)
             y2 = buf(B, 1, D * H * W, dtype=torch.float32)
-            ga = (ptr(h), ptr(g["a"]), ptr(g["b"]), 1, ptr(hg.w), ptr(m.out[2].bias), ptr(y2), B, D, H, W, h.shape[-1])
+            npos = B * D * H * W
+            if train:
+                # the activated input is kept (the head's weight gradient contracts it with the im2col of dpred)
+                xact = buf(B, D, H, W, h.shape[-1])
+                ga0 = (ptr(h), h.shape[-1], None, 0, dtc, B, D * H * W, ptr(g["a"]), ptr(g["b"]), 1, ptr(xact))
+                self.ops.append(lambda s, a=ga0: L.rho_gn_apply(*a, s))
+                self.info.append(dict(kind="gn_apply", flops=0.0, bytes=2.0 * esz * xact.numel()))
+                ga = (ptr(xact), None, None, 0, ptr(hg.w), ptr(m.out[2].bias), ptr(y2), B, D, H, W, h.shape[-1])
+                self.nodes.append(dict(k="head_direct", x=h, pre=g, xact=xact, cw=head, y2=y2, out_dims=(B, D, H, W)))
+            else:
+                ga = (ptr(h), ptr(g["a"]), ptr(g["b"]), 1, ptr(hg.w), ptr(m.out[2].bias), ptr(y2), B, D, H, W, h.shape[-1])
             self.ops.append(lambda s, a=ga: L.rho_head_conv3d(*a, s))
             self.keep.append(g)
-            npos = B * D * H * W
             self.info.append(dict(kind="head", flops=2.0 * npos * h.shape[-1] * 27, bytes=float(esz) * npos * h.shape[-1] + 4.0 * npos))
         elif gemm_ends and head.taps > 1 and head.cout == 1:
             hg = eng._conv_as_gemm(m.out[2], _HeadAsGemm)
@@ -932,9 +1006,26 @@ class _Plan:
             bw.append(fn)
             binfo.append(dict(kind=kind, flops=flops, bytes=nbytes, **shape))
 
-        def gradbuf(t: Tensor):
+        # Residual adds folded into the next GroupNorm-backward apply pass (round 4; RHO_FOLD_ADD=0: a pass of their own as before):
+        # `G[res] += dY` of a residual connection whose target already holds a gradient is NOT launched; the addend waits here
+        # until the apply pass that accumulates into G[res] anyway takes it as `add1` (one read instead of read + read + write).
+        # Any other access to G[res] flushes it as the plain rho_add_inplace first.
+        fold_add = os.environ.get("RHO_FOLD_ADD", "1") != "0"
+        pending_add: Dict[int, Tensor] = {}
+
+        def flush_add(k: int):
+            src = pending_add.pop(k, None)
+            if src is not None:
+                a = (ptr(G[k]), ptr(src), dtc, src.numel())
+                emit(lambda s, a=a: L.rho_add_inplace(*a, s), "add", nbytes=3.0 * esz * src.numel())
+                if src.data_ptr() not in {g_.data_ptr() for g_ in G.values()}:
+                    pool.put(src)
+
+        def gradbuf(t: Tensor, fold_ok: bool = False):
             """(buffer, accumulate?) for a write into the gradient of activation t."""
             k = key(t)
+            if not fold_ok:
+                flush_add(k)
             if k in G:
                 return G[k], (k in written)
             G[k] = pool.get(tuple(t.shape), t.dtype)
@@ -967,6 +1058,65 @@ class _Plan:
             return lambda s: L.rho_conv_nd_wgrad_ws(C.byref(d), dy_ptr, w_, dw_ptr(), db_ptr(), ptr(det_ws["t"]), det_ws["bytes"], s)
         self._det_ws = det_ws
 
+        # ---- weight-gradient accumulation ARENA (round 4; RHO_DW_ARENA=0 restores the shared scratch): every weight-gradient launch
+        # accumulates into a region of its own ([taps][coutp][cinp] fp32 + the channel sums), the whole arena is cleared by ONE memset
+        # at the head of the backward, and the regions are moved into the parameter gradients by ONE table-driven launch per ~32 MiB
+        # of parameters (rho_wgrad_finalize_batch) - instead of a memset + finalize + bias-gradient launch per convolution
+        # (~250 launches of a few microseconds each per step).  Parameters are reported final (bwd_marks) after their batch.
+        use_arena = os.environ.get("RHO_DW_ARENA", "1") != "0"
+        arena: Dict[str, object] = {"t": None, "floats": 0}
+        # (a batch closes at 32 MiB of parameters, or a sixteenth of the model where that is smaller, so that data-parallel buckets
+        #  still become final - and their all-reduce still starts - well inside the backward)
+        fin_batch_bytes = min(int(float(os.environ.get("RHO_FIN_BATCH_MB", "32")) * 2 ** 20),
+                              max(1, sum(4 * cw.weight.numel() for cw in eng._convs) // 16))
+        fin: Dict[str, object] = {"entries": [], "params": [], "bytes": 0}
+        self._arena = arena
+
+        def region(nfloats: int) -> int:
+            off = arena["floats"]
+            arena["floats"] = off + ((int(nfloats) + 63) // 64) * 64
+            return off
+
+        def aptr(off: int) -> Callable[[], int]:
+            return lambda: arena["t"].data_ptr() + 4 * off
+
+        def fin_add(**e):
+            fin["entries"].append(e)
+
+        def fin_close(force: bool = False):
+            """Emit the batched finalize of the pending regions (and report their parameters final) once enough bytes are pending."""
+            if not fin["entries"] or (not force and fin["bytes"] < fin_batch_bytes):
+                return
+            entries, params = fin["entries"], fin["params"]
+            fin["entries"], fin["params"], fin["bytes"] = [], [], 0
+            state = {"sig": None, "dev": None, "blocks": 0}
+
+            def run(s, entries=entries, state=state):
+                sig = (arena["t"].data_ptr(),) + tuple(pgrad(e["param"]) for e in entries)
+                if sig != state["sig"]:
+                    raw, blk = [], 0
+                    for e in entries:
+                        op = hip.WfinOp()
+                        op.dw, op.grad, op.row_src = arena["t"].data_ptr() + 4 * e["off"], pgrad(e["param"]), e["rs"]
+                        op.cout, op.cin, op.coutp, op.cinb = e["cout"], e["cin"], e["coutp"], e["cinb"]
+                        op.kd, op.kh, op.kw = e["k"]
+                        op.total = e["cout"] * e["cin"] * e["k"][0] * e["k"][1] * e["k"][2]
+                        op.kind, op.up_h, op.up_w, op.phase_stride = e["kind"], e.get("up_h", 0), e.get("up_w", 0), e.get("stride", 0)
+                        op.nblk = max(1, min((op.total + 255) // 256, 512))
+                        op.blk0 = blk
+                        blk += op.nblk
+                        raw.append(bytes(op))
+                    state["dev"] = torch.frombuffer(bytearray(b"".join(raw)), dtype=torch.uint8).to(dev)
+                    state["blocks"], state["sig"] = blk, sig
+                return L.rho_wgrad_finalize_batch(state["dev"].data_ptr(), len(entries), state["blocks"], s)
+            emit(run, "wgrad_finalize", nbytes=12.0 * sum(e["cout"] * e["cin"] * e["k"][0] * e["k"][1] * e["k"][2] for e in entries))
+            self.keep.append(state)
+            self.bwd_marks.append((len(bw), params))
+
+        if use_arena:
+            emit(lambda s: (arena["t"].zero_(), 0)[1], "memset")
+            arena_memset_info = binfo[-1]
+
         def bias_and_wgrad(node, dY: Tensor, dyw: int):
             cw = node["cw"]
             N, Do, Ho, Wo = node["out_dims"]
@@ -984,6 +1134,27 @@ class _Plan:
                 # Upsample + conv ran as sub-pixel phases: per phase a 2-tap weight gradient on the SOURCE tensor against that parity
                 # of dY (12 / 27 of the multiply-adds, no upsampled copy), routed back to the 3-tap parameter gradient
                 x1 = node["x1"]
+                if use_arena:
+                    nwp = max(kk[0] * kk[1] * kk[2] for kk in [(cw.kernel[0], 2 if ph_[0] else cw.kernel[1], 2 if ph_[1] else cw.kernel[2])
+                                                                for ph_, _ in cw.wph]) * cw.coutp * cw.cinp
+                    stride_ = ((nwp + 63) // 64) * 64
+                    off_b, off0 = region(max(dyw, cw.coutp)), region(stride_ * len(cw.wph))
+                    for idx, (ph, wt) in enumerate(cw.wph):
+                        kern = (cw.kernel[0], 2 if ph[0] else cw.kernel[1], 2 if ph[1] else cw.kernel[2])
+                        d = ops.make_conv_desc(x1, None, wt, cw.b, kernel=kern, cout=cw.cout, split=cw.cout, y=dY, y2=None, phase_hw=ph)
+                        self.keep.append(d)
+                        self.wgrad_descs.append((d, dyw))
+                        emit(wgrad_call(d, ptr(dY), dyw, aptr(off0 + idx * stride_), aptr(off_b)), "wgrad",
+                             flops=2.0 * N * S * cw.cout * cw.cin * cw.taps / len(cw.wph),
+                             nbytes=float(esz) * (x1.numel() + dY.numel() / len(cw.wph)),
+                             cin=cw.cin, cout=cw.cout, taps=cw.taps, positions=N * S // len(cw.wph))
+                    up_h_, up_w_ = int(any(ph[0] for ph, _ in cw.wph)), int(any(ph[1] for ph, _ in cw.wph))
+                    fin_add(kind=1, off=off0, param=cw.weight, rs=None, cout=cw.cout, cin=cw.cin, coutp=cw.coutp, cinb=cw.cinp, k=cw.kernel,
+                            up_h=up_h_, up_w=up_w_, stride=stride_)
+                    fin_add(kind=0, off=off_b, param=cw.bias_param, rs=rs, cout=cw.cout, cin=1, coutp=dyw, cinb=1, k=(1, 1, 1))
+                    fin["params"] += [cw.weight, cw.bias_param]
+                    fin["bytes"] += 4 * cw.weight.numel()
+                    return
                 cbv = c_tmp[:max(dyw, cw.coutp)]
                 emit(lambda s, t2=cbv: (t2.zero_(), 0)[1], "memset", nbytes=4.0 * cbv.numel())
                 for ph, wt in cw.wph:
@@ -1034,6 +1205,20 @@ class _Plan:
             self.keep.append(d)
             self.wgrad_descs.append((d, dyw))
             nw = cw.taps * cw.coutp * cw.cinp
+            if use_arena:
+                off_w, off_b = region(nw), region(max(dyw, cw.coutp))
+                emit(wgrad_call(d, ptr(dY), dyw, aptr(off_w), aptr(off_b)), "wgrad",
+                     flops=2.0 * N * S * cw.cout * cw.cin * cw.taps, nbytes=float(esz) * (x1.numel() + dY.numel()),
+                     cin=cw.cin, cout=cw.cout, taps=cw.taps, positions=N * S)
+                fin_add(kind=0, off=off_w, param=cw.weight, rs=rs, cout=cw.cout, cin=cw.cin, coutp=cw.coutp, cinb=cw.cinp, k=cw.kernel)
+                fin_add(kind=0, off=off_b, param=cw.bias_param, rs=rs, cout=cw.cout, cin=1, coutp=dyw, cinb=1, k=(1, 1, 1))
+                fin["params"] += [cw.weight, cw.bias_param]
+                fin["bytes"] += 4 * cw.weight.numel()
+                if tmp_up is not None:
+                    pool.put(tmp_up)
+                if xact is not None:
+                    pool.put(xact)
+                return
             dwv = dwbuf[:nw]
             cbv = c_tmp[:max(dyw, cw.coutp)]
             emit(lambda s, t=dwv, t2=cbv: (t.zero_(), t2.zero_(), 0)[2], "memset", nbytes=4.0 * nw)
@@ -1058,7 +1243,8 @@ class _Plan:
             c2 = x2.shape[-1] if x2 is not None else 0
             norm = pre["norm"]
             Cc, N_, S_ = pre["C"], pre["N"], pre["S"]
-            g1, acc1 = gradbuf(x1)
+            g1, acc1 = gradbuf(x1, fold_ok=True)
+            add1 = pending_add.pop(key(x1), None)              # a residual's gradient waiting to join G[x1]: folded into this pass
             g2, acc2 = gradbuf(x2) if x2 is not None else (None, False)
             cA = pool.get((N_, Cc), torch.float32)
             cP = pool.get((N_, 32), torch.float32)
@@ -1084,8 +1270,11 @@ class _Plan:
                      ptr(work), pgrad(norm.weight), pgrad(norm.bias), 1, dscale, dshift, film_stride, ptr(cA), ptr(cP),
                      ptr(cQ), s), "gn_bwd_finalize")
             a3 = (ptr(dact), ptr(x1), c1, ptr(x2), c2, dtc, N_, S_, ptr(pre["a"]), ptr(pre["b"]), int(pre_silu),
-                  ptr(cA), ptr(cP), ptr(cQ), ptr(g1), ptr(g2), int(acc1), int(acc2))
-            emit(lambda s, a=a3: L.rho_gn_bwd_apply(*a, s), "gn_bwd_apply", nbytes=3.0 * esz * N_ * S_ * Cc)
+                  ptr(cA), ptr(cP), ptr(cQ), ptr(g1), ptr(g2), int(acc1), int(acc2), ptr(add1))
+            emit(lambda s, a=a3: L.rho_gn_bwd_apply(*a, s), "gn_bwd_apply",
+                 nbytes=esz * N_ * S_ * (3.0 * Cc + (c1 if acc1 else 0) + (c2 if acc2 else 0) + (c1 if add1 is not None else 0)))
+            if add1 is not None and add1.data_ptr() not in {g_.data_ptr() for g_ in G.values()}:
+                pool.put(add1)                                 # (stream order: recycled buffers are written by later launches only)
             written.add(key(x1))
             if x2 is not None:
                 written.add(key(x2))
@@ -1178,18 +1367,87 @@ class _Plan:
         # ---- head: dpred [N, Cout, S] float32 -> channels-last, as wide as the dgrad weights expect
         self.dpred_in = torch.empty(tuple(self.out.shape), dtype=torch.float32, device=dev)
         head = self.nodes[-1]
-        hw = head["cw"].wd.shape[2]
-        N, Do, Ho, Wo = head["out_dims"]
-        dhead = pool.get((N, Do, Ho, Wo, hw), dt)
-        a = (ptr(self.dpred_in), ptr(dhead), dtc, N, head["cw"].cout, Do * Ho * Wo, hw)
-        emit(lambda s, a=a: L.rho_pack_input(*a, s), "pack")
-        G[key(head["y2"])] = dhead
-        written.add(key(head["y2"]))
+
+        def im2col_of(src_f32: Tensor, dims4):
+            """[N, 1, D, H, W] float32 -> channels-last [N, D, H, W, 32] (27 taps + zero pad), the K = 32 operand of the GEMM forms."""
+            N_, D_, H_, W_ = dims4
+            im = pool.get((N_, D_, H_, W_, 32), dt)
+            a_ = (ptr(src_f32), ptr(im), dtc, N_, 1, D_, H_, W_, 3, 3, 3, 32)
+            emit(lambda s, a=a_: L.rho_im2col_taps(*a, s), "pack", nbytes=4.0 * src_f32.numel() + float(esz) * im.numel())
+            return im
+
+        def gemm_wgrad(x_t: Tensor, dy_t: Tensor, rows: int):
+            """dw[rows][cin] (+ channel sums of dy_t) = sum_pos dy_t[pos][:rows] x_t[pos][:] on the GEMM-shaped k_wgrad1; returns the
+            arena offsets (weights, channel sums)."""
+            cin_ = x_t.shape[-1]
+            dummy_w = torch.empty(1, rows, cin_, dtype=dt, device=dev)
+            dummy_b = torch.zeros(rows, dtype=torch.float32, device=dev)
+            self.keep.extend([dummy_w, dummy_b])
+            d = ops.make_conv_desc(x_t, None, dummy_w, dummy_b, kernel=(1, 1, 1), cout=rows, split=rows, y=dy_t, y2=None)
+            self.keep.append(d)
+            self.wgrad_descs.append((d, dy_t.shape[-1]))
+            off_w, off_b = region(rows * cin_), region(max(rows, dy_t.shape[-1]))
+            npos_ = x_t.numel() // cin_
+            emit(wgrad_call(d, ptr(dy_t), dy_t.shape[-1], aptr(off_w), aptr(off_b)), "wgrad", flops=2.0 * npos_ * 27 * max(rows, cin_),
+                 nbytes=float(esz) * (x_t.numel() + dy_t.numel()), cin=cin_, cout=rows, taps=1, positions=npos_)
+            return off_w, off_b
+
+        if head["k"] == "head_direct":
+            # one-output-channel head conv (unet_v2.py:679-683): data gradient = rho_stem_conv3d on dpred with mirrored taps; weight
+            # gradient = GEMM of the kept activated input against the im2col of dpred (rows = taps, mirrored back by finalize kind 2);
+            # bias gradient = the im2col's centre column sum (tap 13 never touches the padding) = sum of dpred
+            hcw = head["cw"]
+            N, Do, Ho, Wo = head["out_dims"]
+            Ch = head["x"].shape[-1]
+            hdw = eng._head_dgrad(m.out[2])
+            dact = pool.get((N, Do, Ho, Wo, Ch), dt)
+            a = (ptr(self.dpred_in), ptr(hdw.w), ptr(hdw.zero_bias), ptr(dact), None, N, Do, Ho, Wo, Ch)
+            emit(lambda s, a=a: L.rho_stem_conv3d(*a, s), "dgrad", flops=2.0 * N * Do * Ho * Wo * Ch * 27,
+                 nbytes=4.0 * N * Do * Ho * Wo + float(esz) * dact.numel())
+            im = im2col_of(self.dpred_in, (N, Do, Ho, Wo))
+            off_w, off_b = gemm_wgrad(head["xact"], im, 32)
+            pool.put(im)
+            fin_add(kind=2, off=off_w, param=hcw.weight, rs=None, cout=1, cin=Ch, coutp=32, cinb=Ch, k=(3, 3, 3))   # (walks [ci][tap])
+            fin_add(kind=0, off=off_b + 13, param=hcw.bias_param, rs=None, cout=1, cin=1, coutp=1, cinb=1, k=(1, 1, 1))
+            fin["params"] += [hcw.weight, hcw.bias_param]
+            fin["bytes"] += 4 * hcw.weight.numel()
+            gn_backward(head["pre"], True, head["x"], None, dact)
+            pool.put(dact)
+            self.bwd_marks.append((len(bw), [head["pre"]["norm"].weight, head["pre"]["norm"].bias]))
+        else:
+            hw = head["cw"].wd.shape[2]
+            N, Do, Ho, Wo = head["out_dims"]
+            dhead = pool.get((N, Do, Ho, Wo, hw), dt)
+            a = (ptr(self.dpred_in), ptr(dhead), dtc, N, head["cw"].cout, Do * Ho * Wo, hw)
+            emit(lambda s, a=a: L.rho_pack_input(*a, s), "pack")
+            G[key(head["y2"])] = dhead
+            written.add(key(head["y2"]))
 
         rs_hw = (1, 1) if eng.dims >= 2 else (0, 1)
         for node in reversed(self.nodes):
+            if node["k"] == "head_direct":
+                continue                                       # (handled above)
+            if node["k"] == "stem_direct":
+                # one-input-channel stem conv (unet_v2.py:535): weight gradient = GEMM of the im2col of the input against dY
+                # (dw[co][tap], the parameter's own layout), bias gradient = channel sums of dY; no data gradient
+                flush_add(key(node["y"]))
+                dY = G.pop(key(node["y"]), None)
+                if dY is None:
+                    raise hip.RhoHipError("internal: missing gradient of the stem output in the backward plan")
+                scw = node["cw"]
+                im = im2col_of(self.x_in, node["out_dims"])
+                off_w, off_b = gemm_wgrad(im, dY, scw.cout)
+                pool.put(im)
+                pool.put(dY)
+                fin_add(kind=0, off=off_w, param=scw.weight, rs=None, cout=scw.cout, cin=27, coutp=scw.cout, cinb=32, k=(1, 1, 1))
+                fin_add(kind=0, off=off_b, param=scw.bias_param, rs=None, cout=scw.cout, cin=1, coutp=dY.shape[-1], cinb=1, k=(1, 1, 1))
+                fin["params"] += [scw.weight, scw.bias_param]
+                fin["bytes"] += 4 * scw.weight.numel()
+                fin_close()
+                continue
             if node["k"] == "resample":
                 # y = avgpool / nearest-upsample(x): the transposed map into the gradient of x (accumulating if x has other consumers)
+                flush_add(key(node["y"]))
                 dy = G.pop(key(node["y"]), None)
                 if dy is None:
                     raise hip.RhoHipError("internal: missing gradient of a resampled tensor in the backward plan")
@@ -1204,6 +1462,7 @@ class _Plan:
                 pool.put(dy)
                 continue
             if node["k"] == "act":
+                flush_add(key(node["y"]))
                 dact = G.pop(key(node["y"]), None)
                 if dact is None:
                     raise hip.RhoHipError("internal: missing gradient of a materialised activation in the backward plan")
@@ -1213,6 +1472,7 @@ class _Plan:
                 self.bwd_marks.append((len(bw), [pre["norm"].weight, pre["norm"].bias]))
                 continue
             if node["k"] == "attn":
+                flush_add(key(node["ao"]))
                 dao = G.get(key(node["ao"]))
                 N, T, Cc = node["N"], node["T"], node["C"]
                 dqkv = pool.get(tuple(node["qk"].shape[:4]) + (3 * Cc,), dt)   # = dY of the qkv projection
@@ -1227,17 +1487,23 @@ class _Plan:
                 continue
             cw = node["cw"]
             out_t = node["y"] if node["y"] is not None else node["y2"]
+            flush_add(key(out_t))
             dY = G.get(key(out_t))
             if dY is None:
                 raise hip.RhoHipError("internal: missing output gradient in backward plan")
             dyw = dY.shape[-1]
+            held_for_add = False
             # residual input of the epilogue: alias (first contribution) or accumulate
             if node["res"] is not None:
                 rk = key(node["res"])
                 if rk not in G:
                     G[rk] = dY
                     written.add(rk)
+                elif fold_add and rk not in pending_add and G[rk].shape == dY.shape:
+                    pending_add[rk] = dY                       # joins G[rk] in the next apply pass that accumulates into it
+                    held_for_add = True
                 else:
+                    flush_add(rk)
                     a = (ptr(G[rk]), ptr(dY), dtc, dY.numel())
                     emit(lambda s, a=a: L.rho_add_inplace(*a, s), "add", nbytes=3.0 * esz * dY.numel())
             bias_and_wgrad(node, dY, dyw)
@@ -1246,13 +1512,23 @@ class _Plan:
             # the output gradient is dead now unless a residual aliased it
             aliased = node["res"] is not None and G.get(key(node["res"])) is dY
             G.pop(key(out_t), None)
-            if not aliased:
+            if not aliased and not held_for_add:
                 pool.put(dY)
-            ps = [cw.weight, cw.bias_param]
+            ps = [] if use_arena else [cw.weight, cw.bias_param]      # (arena: reported with their finalize batch)
             if node["pre"] is not None:
                 ps += [node["pre"]["norm"].weight, node["pre"]["norm"].bias]
-            self.bwd_marks.append((len(bw), ps))
+            if ps:
+                self.bwd_marks.append((len(bw), ps))
+            if use_arena:
+                fin_close()
 
+        if pending_add:
+            raise hip.RhoHipError("internal: a residual gradient was never added (backward plan)")
+        if use_arena:
+            fin_close(force=True)
+            arena["t"] = torch.empty(max(arena["floats"], 64), dtype=torch.float32, device=dev)
+            arena_memset_info["bytes"] = 4.0 * arena["t"].numel()
+            pool.all.append(arena["t"])
         # ---- embedding path (needs the FiLM gradients of every block)
         e = 4 * eng.mc
         first = True
@@ -1352,7 +1628,9 @@ class _Plan:
                 p_.grad = torch.zeros_like(p_)
         self.dpred_in.copy_(dpred.reshape(self.dpred_in.shape))
         s = hip.stream()
-        marks = {i: ps for i, ps in self.bwd_marks}
+        marks: Dict[int, list] = {}
+        for i, ps in self.bwd_marks:
+            marks.setdefault(i, []).extend(ps)
         for i, op in enumerate(self.bwd):
             rc = op(s)
             if rc != 0:

@@ -56,6 +56,16 @@ class PrepOp(C.Structure):
 PREP_FWD, PREP_DGRAD, PREP_PHASE, PREP_SEL, PREP_VEC = 0, 1, 2, 3, 4
 
 
+class WfinOp(C.Structure):
+    """struct rho_wfin_op (include/rho_hip.h): one accumulation buffer -> parameter gradient in rho_wgrad_finalize_batch's table."""
+    _fields_ = [
+        ("dw", c_void_p), ("grad", c_void_p), ("row_src", c_void_p),
+        ("cout", c_int64), ("cin", c_int64), ("coutp", c_int64), ("cinb", c_int64), ("total", c_int64), ("phase_stride", c_int64),
+        ("kind", c_int32), ("kd", c_int32), ("kh", c_int32), ("kw", c_int32), ("up_h", c_int32), ("up_w", c_int32),
+        ("blk0", c_int32), ("nblk", c_int32),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/rho_hip.h declares
 SIGNATURES = {
     "rho_abi_version": (c_int, []),
@@ -81,6 +91,7 @@ SIGNATURES = {
     "rho_pack_input": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     "rho_prep_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "rho_prep_batch": (c_int, [c_void_p, c_int64, c_int64, c_void_p]),
+    "rho_wgrad_finalize_batch": (c_int, [c_void_p, c_int64, c_int64, c_void_p]),
     "rho_prep_conv_weight_sel": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_int64, c_int64, c_int, c_void_p]),
     "rho_prep_conv_weight_phase": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64,
@@ -118,7 +129,7 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                     c_void_p]),
     "rho_gn_bwd_apply": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int,
-                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "rho_gn_apply": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "rho_ddpm_sched_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_float,
                                     c_float, c_float, c_void_p]),

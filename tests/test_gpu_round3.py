@@ -231,7 +231,9 @@ def test_use_checkpoint_recomputes_in_backward_same_gradients_less_memory(case, 
     for n, gr in res[False][1].items():
         d = float((res[True][1][n].double() - gr.double()).norm())
         assert d <= 1e-5 * float(gr.double().norm()) + 1e-9, (n, d)
-    assert res[True][2] < 0.9 * res[False][2], (res[True][2], res[False][2])      # (tiny nets: 0.81; c3 at B = 32: see DESIGN.md)
+    # (tiny nets: 0.81 of the activations' bytes, 0.92 with the round-4 weight-gradient arena - one fp32 region per parameter, the
+    #  same in both plans - counted in; c3 at B = 32: see DESIGN.md)
+    assert res[True][2] < 0.95 * res[False][2], (res[True][2], res[False][2])
 
 
 # ----------------------------------------------------------------------------- HDF5 replay of the synthetic dataset

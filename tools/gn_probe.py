@@ -50,7 +50,7 @@ def main():
         print(f"C={c1}+{c2} S={S}: gn_bwd_reduce {t:7.3f} ms {2 * el / t / 1e9:6.2f} TB/s")
         for acc in (0, 1):
             t = timed(lambda: check(L.rho_gn_bwd_apply(ptr(g), ptr(x1), c1, ptr(x2), c2, dt, N, S, ptr(a), ptr(b), 1, ptr(cA), ptr(cP),
-                                                       ptr(cQ), ptr(dx1), ptr(dx2), acc, acc, stream()), "b"))
+                                                       ptr(cQ), ptr(dx1), ptr(dx2), acc, acc, None, stream()), "b"))
             print(f"C={c1}+{c2} S={S}: gn_bwd_apply acc={acc} {t:7.3f} ms {(3 + acc) * el / t / 1e9:6.2f} TB/s")
         del g, x1, x2, dx1, dx2, y
         torch.cuda.empty_cache()
