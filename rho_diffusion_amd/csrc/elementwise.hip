@@ -757,6 +757,51 @@ __global__ __launch_bounds__(256) void k_prep_batch(const rho_prep_op* __restric
         if (ops[mid].blk0 <= b) lo = mid; else hi = mid - 1;
     }
     const rho_prep_op o = ops[lo];
+    const int taps_ = o.kd * o.kh * o.kw;
+    if ((o.kind == RHO_PREP_FWD || o.kind == RHO_PREP_DGRAD) && taps_ > 1 && taps_ <= 32) {
+        // [row][channel][tap] -> [tap][..][..] through LDS (the elementwise walk reads the parameter with a stride of `taps` floats
+        // between consecutive threads: 0.5 TB/s).  A unit = 64 consecutive entries of the output's contiguous axis for one entry of
+        // its middle axis: FWD (co, 64 ci): one contiguous read of 64 * taps floats;  DGRAD (ci, 64 co): 64 runs of `taps` floats.
+        // Either way every tap is written as one run of 64 contiguous outputs.
+        __shared__ float tile[64 * 33];
+        const bool fwd = o.kind == RHO_PREP_FWD;
+        const int64_t mid = o.d1, inner = o.d2;                   // out [taps][d1][d2]
+        const int64_t groups = (inner + 63) / 64;
+        const int64_t units = mid * groups;
+        for (int64_t u = b - o.blk0; u < units; u += o.nblk) {
+            const int64_t m_ = u / groups;
+            const int64_t i0 = (u % groups) * 64;
+            for (int e = threadIdx.x; e < 64 * taps_; e += 256) {
+                float v = 0.0f;
+                if (fwd) {
+                    // m_ = output row co (maybe permuted / padded), inner = ci: source run w[src][i0 .. i0 + 63][taps]
+                    const int64_t src = o.perm ? (int64_t)o.perm[m_] : (m_ < o.cout ? m_ : -1);
+                    const int64_t ci = i0 + e / taps_;
+                    if (src >= 0 && src < o.cout && ci < o.cin) v = o.w[(src * o.cin + i0) * taps_ + e];
+                    tile[(e / taps_) * 33 + e % taps_] = v;
+                } else {
+                    // m_ = row = input channel ci, inner = col = output channel (maybe permuted): run w[src(col)][m_][taps]
+                    const int c = e / taps_, t = e % taps_;
+                    const int64_t col = i0 + c;
+                    const int64_t src = col < o.cout ? (o.perm ? (int64_t)o.perm[col] : col) : -1;
+                    if (src >= 0 && src < o.cout && m_ < o.cin) v = o.w[(src * o.cin + m_) * taps_ + t];
+                    tile[c * 33 + t] = v;
+                }
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < 64 * taps_; e += 256) {
+                const int t = e >> 6, c = e & 63;
+                if (i0 + c < inner) {
+                    const float v = tile[c * 33 + (fwd ? t : taps_ - 1 - t)];
+                    const int64_t oi = ((int64_t)t * mid + m_) * inner + i0 + c;
+                    if (o.dtype == RHO_BF16) reinterpret_cast<bf16_raw*>(o.out)[oi] = f32_to_bf16(v);
+                    else reinterpret_cast<float*>(o.out)[oi] = v;
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
     const int64_t stride = (int64_t)o.nblk * 256;
     for (int64_t i = (int64_t)(b - o.blk0) * 256 + threadIdx.x; i < o.total; i += stride) {
         const float v = prep_elem(o, i);

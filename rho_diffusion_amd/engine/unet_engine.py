@@ -206,6 +206,26 @@ class _HeadAsGemm(_ConvW):
         return True                                  # (b stays zero: the bias is added by the kernel that folds the taps)
 
 
+
+    def __init__(self, weight: nn.Parameter, bias: nn.Parameter, dtype):
+        self.taps3 = int(weight[0, 0].numel())
+        self.kernel3 = tuple([1] * (3 - (weight.dim() - 2)) + [int(v) for v in weight.shape[2:]])
+        super().__init__(weight, bias, dtype)
+
+    def _geometry(self):
+        self.kernel, self.taps = (1, 1, 1), 1
+        self.cout = 32
+
+    def _source(self) -> Tensor:
+        w = self.weight.detach()[0].reshape(self.cin, self.taps3).t()          # [taps, cin]
+        full = torch.zeros(32, self.cin, 1, 1, 1, dtype=w.dtype, device=w.device)
+        full[: self.taps3, :, 0, 0, 0] = w
+        return full
+
+    def _bias_source(self) -> Tensor:
+        return torch.zeros(32, dtype=torch.float32, device=self.weight.device)
+
+
 class _HeadDgradW:
     """Data-gradient weights of a one-output-channel 3x3x3 head conv in the layout rho_stem_conv3d reads ([1][C][32], taps as the
     contraction): dact[pos][c] = sum_tap W[0][c][tap] dpred[pos - (tap - 1)] is that kernel run on dpred with the taps mirrored,
@@ -239,24 +259,6 @@ class _HeadDgradW:
         src = self.weight.detach().reshape(-1).float()
         g = torch.where(self._perm >= 0, src[self._perm.clamp(min=0).long()], torch.zeros((), device=src.device))   # (data movement only)
         self.w.copy_(g.view_as(self.w))
-
-    def __init__(self, weight: nn.Parameter, bias: nn.Parameter, dtype):
-        self.taps3 = int(weight[0, 0].numel())
-        self.kernel3 = tuple([1] * (3 - (weight.dim() - 2)) + [int(v) for v in weight.shape[2:]])
-        super().__init__(weight, bias, dtype)
-
-    def _geometry(self):
-        self.kernel, self.taps = (1, 1, 1), 1
-        self.cout = 32
-
-    def _source(self) -> Tensor:
-        w = self.weight.detach()[0].reshape(self.cin, self.taps3).t()          # [taps, cin]
-        full = torch.zeros(32, self.cin, 1, 1, 1, dtype=w.dtype, device=w.device)
-        full[: self.taps3, :, 0, 0, 0] = w
-        return full
-
-    def _bias_source(self) -> Tensor:
-        return torch.zeros(32, dtype=torch.float32, device=self.weight.device)
 
 
 class _Pool:

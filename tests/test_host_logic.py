@@ -187,3 +187,24 @@ def test_unetv2_refuses_dropout_and_foreign_activations_naming_the_reference_lin
     with pytest.raises(NotImplementedError, match=r"unet_v2\.py:518-519"):
         UNet(**kw, activation="ReLU")
     UNet(**kw, dropout=0.0, activation="SiLU")
+
+
+def test_head_dgrad_weight_layout_is_the_mirrored_taps_as_contraction_form():
+    """engine._HeadDgradW (round 4): w[0][c][t] = weight[0][c][26 - t] for t < 27, zero beyond - what rho_stem_conv3d needs to compute
+    the data gradient of the one-output-channel head conv from dpred (host-side index table, checked without a GPU)."""
+    from rho_diffusion_amd.engine.unet_engine import _HeadDgradW
+    w = torch.nn.Parameter(torch.arange(1 * 4 * 27, dtype=torch.float32).reshape(1, 4, 3, 3, 3))
+    hd = _HeadDgradW(w, torch.float32)
+    assert hd.w.shape == (1, 4, 32)
+    for c in range(4):
+        for t in range(27):
+            assert float(hd.w[0, c, t]) == float(w[0, c].reshape(-1)[26 - t])
+        assert float(hd.w[0, c, 27:].abs().max()) == 0.0
+
+
+def test_prep_and_finalize_table_records_match_the_header_structs():
+    """ctypes mirrors of rho_prep_op / rho_wfin_op (include/rho_hip.h): sizes and field offsets the kernels index by."""
+    import ctypes as C
+    from rho_diffusion_amd import hip
+    assert C.sizeof(hip.PrepOp) == 128 and hip.PrepOp.total.offset == 56 and hip.PrepOp.kind.offset == 64 and hip.PrepOp.blk0.offset == 116
+    assert C.sizeof(hip.WfinOp) == 104 and hip.WfinOp.phase_stride.offset == 64 and hip.WfinOp.kind.offset == 72 and hip.WfinOp.blk0.offset == 96
