@@ -1530,6 +1530,7 @@ class _Plan:
             fin_close(force=True)
             arena["t"] = torch.empty(max(arena["floats"], 64), dtype=torch.float32, device=dev)
             arena_memset_info["bytes"] = 4.0 * arena["t"].numel()
+            self.arena_bytes = 4 * arena["t"].numel()           # (a fixed cost of the model's size, whatever the plan keeps of activations)
             pool.all.append(arena["t"])
         # ---- embedding path (needs the FiLM gradients of every block)
         e = 4 * eng.mc

@@ -226,14 +226,13 @@ def test_use_checkpoint_recomputes_in_backward_same_gradients_less_memory(case, 
         loss = mse_loss(pred, det_normal(tuple(pred.shape), case + "tgt").to(DEV))
         loss.backward()
         plan = model.engine()._last_train_plan
-        res[ck] = (float(loss), {n: p.grad.clone() for n, p in model.named_parameters()}, plan.nbytes())
+        # (activation bytes: the weight-gradient arena of round 4 - one fp32 region per parameter - is the same in both plans)
+        res[ck] = (float(loss), {n: p.grad.clone() for n, p in model.named_parameters()}, plan.nbytes() - getattr(plan, "arena_bytes", 0))
     assert res[True][0] == res[False][0]
     for n, gr in res[False][1].items():
         d = float((res[True][1][n].double() - gr.double()).norm())
         assert d <= 1e-5 * float(gr.double().norm()) + 1e-9, (n, d)
-    # (tiny nets: 0.81 of the activations' bytes, 0.92 with the round-4 weight-gradient arena - one fp32 region per parameter, the
-    #  same in both plans - counted in; c3 at B = 32: see DESIGN.md)
-    assert res[True][2] < 0.95 * res[False][2], (res[True][2], res[False][2])
+    assert res[True][2] < 0.9 * res[False][2], (res[True][2], res[False][2])      # (tiny nets: 0.81; c3 at B = 32: see DESIGN.md)
 
 
 # ----------------------------------------------------------------------------- HDF5 replay of the synthetic dataset
