@@ -512,7 +512,7 @@ class UNetEngine:
     # environment switches a plan reads while it is built (A/B knobs): part of the plan key, so flipping one rebuilds the plan
     _PLAN_ENV = ("RHO_TRAIN_MATERIALIZE", "RHO_MATERIALIZE_MIN_COUT", "RHO_PHASE_UPSAMPLE", "RHO_PHASE_UPSAMPLE_BWD", "RHO_PHASE_MIN_WGS",
                  "RHO_FOLD_SKIP", "RHO_FOLD_SKIP_TRAIN", "RHO_S2_SPLIT", "RHO_S2_SPLIT_BWD", "RHO_FUSE_GN_BWD", "RHO_GEMM_ENDS",
-                 "RHO_DIRECT_ENDS", "RHO_CONV_SPLITK", "RHO_BATCH_PREP", "RHO_DW_ARENA", "RHO_FOLD_ADD", "RHO_FIN_BATCH_MB")
+                 "RHO_DIRECT_ENDS", "RHO_CONV_SPLITK", "RHO_BATCH_PREP", "RHO_DW_ARENA", "RHO_FOLD_ADD", "RHO_FIN_BATCH_MB", "RHO_BWD_OVERLAP", "RHO_DIRECT_ENDS_TRAIN")
 
     def _plan_signature(self) -> tuple:
         """Everything besides (shape, labels, mode) that is baked into a plan when it is built: the per-ResBlock ``use_checkpoint``
@@ -1004,9 +1004,64 @@ class _Plan:
         def key(t: Tensor) -> int:
             return t.data_ptr()
 
+        # ---- overlap of the HBM-bound GroupNorm backward with the weight gradient (round 4; RHO_BWD_OVERLAP=0: one stream).  Per
+        # normalised conv the order on the launch stream was  wgrad | dgrad | gn_bwd reduce / finalize / apply  - three kernels that
+        # cannot share the chip (two matrix-bound, one at HBM rate: 24 ms of passes per c3 step with the matrix cores idle).  The
+        # weight gradient is off the critical path (it needs dY only), so it now goes to a SIDE stream right after the data gradient:
+        #     main:  dgrad ............ | gn_bwd reduce, finalize, apply | (wait) next node
+        #     side:                     | wgrad ....................... |
+        # one wave per SIMD of k_wgrad leaves registers and wave slots for the elementwise passes, which run in its shadow.  Only
+        # this pair overlaps: the next node's launches wait for the side stream (two matrix-bound kernels sharing the CUs cost more in
+        # L2 locality than they return - measured in round 3).  Pool buffers released by the weight-gradient path are recycled after
+        # that wait only.
+        overlap = os.environ.get("RHO_BWD_OVERLAP", "1") != "0"
+        self._side = torch.cuda.Stream(device=dev) if overlap else None
+        self._overlap_on = True                      # profile() turns it off: per-launch timings need the serial order
+        defer: Dict[str, object] = {"on": False, "ops": [], "puts": []}
+
         def emit(fn, kind, flops=0.0, nbytes=0.0, **shape):
+            info = dict(kind=kind, flops=flops, bytes=nbytes, **shape)
+            if defer["on"]:
+                defer["ops"].append((fn, info))
+                return
             bw.append(fn)
-            binfo.append(dict(kind=kind, flops=flops, bytes=nbytes, **shape))
+            binfo.append(info)
+
+        def wput(t: Tensor):
+            """pool.put for buffers the weight-gradient path read: held back while that path is being deferred to the side stream."""
+            if defer["on"]:
+                defer["puts"].append(t)
+            else:
+                pool.put(t)
+
+        def flush_side():
+            """Emit the deferred weight-gradient launches as side-stream launches (called right after the data-gradient launch)."""
+            for fn, info in defer["ops"]:
+                ev = torch.cuda.Event()
+
+                def run(s, fn=fn, ev=ev):
+                    if not self._overlap_on:
+                        return fn(s)
+                    ev.record(torch.cuda.current_stream())
+                    self._side.wait_event(ev)
+                    return fn(self._side.cuda_stream)
+                bw.append(run)
+                binfo.append(info)
+            defer["ops"] = []
+
+        def join_side():
+            ev = torch.cuda.Event()
+
+            def run(s, ev=ev):
+                if self._overlap_on:
+                    ev.record(self._side)
+                    torch.cuda.current_stream().wait_event(ev)
+                return 0
+            bw.append(run)
+            binfo.append(dict(kind="sync", flops=0.0, bytes=0.0))
+            for t in defer["puts"]:
+                pool.put(t)
+            defer["puts"] = []
 
         # Residual adds folded into the next GroupNorm-backward apply pass (round 4; RHO_FOLD_ADD=0: a pass of their own as before):
         # `G[res] += dY` of a residual connection whose target already holds a gradient is NOT launched; the addend waits here
@@ -1131,7 +1186,7 @@ class _Plan:
                 dst = self.dfilm.data_ptr() + 4 * node["res_add_off"]
                 a = (ptr(dY), dtc, N, S, dyw, ptr(part), dst, film_stride, 0, None, 0)
                 emit(lambda s, a=a: L.rho_chan_sum(*a, s), "chan_sum", nbytes=float(esz) * N * S * dyw)
-            pool.put(part)
+            wput(part)
             if node.get("phased") and node["pre"] is None and node["x2"] is None and self.phase_upsample_bwd:
                 # Upsample + conv ran as sub-pixel phases: per phase a 2-tap weight gradient on the SOURCE tensor against that parity
                 # of dY (12 / 27 of the multiply-adds, no upsampled copy), routed back to the 3-tap parameter gradient
@@ -1217,9 +1272,9 @@ class _Plan:
                 fin["params"] += [cw.weight, cw.bias_param]
                 fin["bytes"] += 4 * cw.weight.numel()
                 if tmp_up is not None:
-                    pool.put(tmp_up)
+                    wput(tmp_up)
                 if xact is not None:
-                    pool.put(xact)
+                    wput(xact)
                 return
             dwv = dwbuf[:nw]
             cbv = c_tmp[:max(dyw, cw.coutp)]
@@ -1233,9 +1288,9 @@ class _Plan:
             emit(lambda s, cw=cw, rs=rs, w_=dyw: L.rho_wgrad_finalize(ptr(c_tmp), pgrad(cw.bias_param), cw.cout, 1, 1, w_, 1, rs, 1, s),
                  "bias_grad")
             if tmp_up is not None:
-                pool.put(tmp_up)
+                wput(tmp_up)
             if xact is not None:
-                pool.put(xact)
+                wput(xact)
 
         def gn_backward(pre, pre_silu, x1, x2, dact, fused=None):
             """dact = gradient of act(GroupNorm(x) * (1 + scale) + shift): reduce / finalize / apply into the gradients of x1 (, x2),
@@ -1283,7 +1338,7 @@ class _Plan:
             for t in (cA, cP, cQ, work):
                 pool.put(t)
 
-        def dgrad(node, dY: Tensor, dyw: int):
+        def dgrad(node, dY: Tensor, dyw: int, after_launch: Optional[Callable[[], None]] = None):
             cw = node["cw"]
             x1, x2, pre = node["x1"], node["x2"], node["pre"]
             c1 = x1.shape[-1]
@@ -1325,6 +1380,8 @@ class _Plan:
                 self.fwd_descs.append(d)
                 emit(lambda s, d=d: L.rho_conv_nd_fwd(C.byref(d), s), "dgrad",
                      flops=2.0 * (dact.numel() // cin) * cin * cw.cout * cw.taps, nbytes=float(esz) * (dY.numel() + dact.numel()))
+                if after_launch is not None:
+                    after_launch()                    # (the deferred weight gradient starts here, on the side stream)
                 if pre is not None:
                     gn_backward(pre, node["pre_silu"], x1, x2, dact, fused)
                     if fused is not None:
@@ -1508,9 +1565,17 @@ class _Plan:
                     flush_add(rk)
                     a = (ptr(G[rk]), ptr(dY), dtc, dY.numel())
                     emit(lambda s, a=a: L.rho_add_inplace(*a, s), "add", nbytes=3.0 * esz * dY.numel())
+            # (normalised convs: the weight gradient runs beside the GroupNorm backward passes, see `overlap` above)
+            ov = overlap and node["pre"] is not None and not node["stem"] and node["up_hw"] == (0, 0)
+            defer["on"] = ov
             bias_and_wgrad(node, dY, dyw)
+            defer["on"] = False
             if not node["stem"]:
-                dgrad(node, dY, dyw)
+                dgrad(node, dY, dyw, after_launch=flush_side if ov else None)
+            if ov:
+                if defer["ops"]:
+                    raise hip.RhoHipError("internal: deferred weight-gradient launches were never issued (backward plan)")
+                join_side()
             # the output gradient is dead now unless a residual aliased it
             aliased = node["res"] is not None and G.get(key(node["res"])) is dY
             G.pop(key(out_t), None)
@@ -1662,6 +1727,7 @@ class _Plan:
         s = hip.stream()
         lst, infos = (self.bwd, self.bwd_info) if backward else (self.ops, self.info)
         tot = [0.0] * len(lst)
+        ov_was, self._overlap_on = getattr(self, "_overlap_on", False), False       # every launch on the timed stream, in order
         for _ in range(repeats):
             evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in lst]
             for op, (e0, e1) in zip(lst, evs):
@@ -1673,4 +1739,5 @@ class _Plan:
             torch.cuda.synchronize()
             for i, (e0, e1) in enumerate(evs):
                 tot[i] += e0.elapsed_time(e1)
+        self._overlap_on = ov_was
         return [dict(info, ms=tot[i] / repeats) for i, info in enumerate(infos)]
