@@ -232,7 +232,9 @@ def test_use_checkpoint_recomputes_in_backward_same_gradients_less_memory(case, 
     for n, gr in res[False][1].items():
         d = float((res[True][1][n].double() - gr.double()).norm())
         assert d <= 1e-5 * float(gr.double().norm()) + 1e-9, (n, d)
-    assert res[True][2] < 0.9 * res[False][2], (res[True][2], res[False][2])      # (tiny nets: 0.81; c3 at B = 32: see DESIGN.md)
+    # (tiny nets: 0.81 in round 3, 0.91 since the round-4 training plans keep a few more fixed-size buffers in BOTH plans - the
+    #  head's activated input, the im2col operands of the 1-channel ends; c3 at B = 32: see DESIGN.md)
+    assert res[True][2] < 0.93 * res[False][2], (res[True][2], res[False][2])
 
 
 # ----------------------------------------------------------------------------- HDF5 replay of the synthetic dataset
