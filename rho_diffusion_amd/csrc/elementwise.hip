@@ -248,10 +248,26 @@ extern "C" int rho_mse(const float* a, const float* b, float* loss, float* grad_
 // Ordered form: block b stores its partial to partials[b]; one wave adds them in index order -> the loss is bit-reproducible
 // (the atomic form above adds the blocks in arrival order).  grad is the same either way.
 __global__ __launch_bounds__(256) void k_mse_part(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ partials,
-                                                  float* __restrict__ grad, int64_t n, float inv_n) {
+                                                  float* __restrict__ grad, int64_t n, float inv_n, int vec) {
     __shared__ float red[4];
     float acc = 0.0f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+    int64_t done = 0;
+    if (vec) {                                   // 16-byte pieces (all three pointers 16-byte aligned): the HBM-rate path
+        const int64_t n4 = n >> 2;
+        const float4* a4 = reinterpret_cast<const float4*>(a);
+        const float4* b4 = reinterpret_cast<const float4*>(b);
+        float4* g4 = reinterpret_cast<float4*>(grad);
+        const float k2 = 2.0f * inv_n;
+        for (int64_t i = tid; i < n4; i += nthr) {
+            const float4 x = a4[i], y = b4[i];
+            const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+            acc += d0 * d0; acc += d1 * d1; acc += d2 * d2; acc += d3 * d3;
+            if (grad) g4[i] = make_float4(k2 * d0, k2 * d1, k2 * d2, k2 * d3);
+        }
+        done = n4 << 2;
+    }
+    for (int64_t i = done + tid; i < n; i += nthr) {
         const float d = a[i] - b[i];
         acc += d * d;
         if (grad) grad[i] = 2.0f * d * inv_n;
@@ -273,7 +289,8 @@ extern "C" int rho_mse_ws(const float* a, const float* b, float* loss, float* gr
     if (!a || !b || !loss || !partials || n <= 0 || n_partials < 1) return RHO_E_ARG;
     int64_t g = grid_for(n, 256 * 8);
     if (g > n_partials) g = n_partials;
-    hipLaunchKernelGGL(k_mse_part, dim3((unsigned)g), dim3(256), 0, as_stream(stream), a, b, partials, grad_a, n, 1.0f / (float)n);
+    const int vec = ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)grad_a) & 15) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(k_mse_part, dim3((unsigned)g), dim3(256), 0, as_stream(stream), a, b, partials, grad_a, n, 1.0f / (float)n, vec);
     hipLaunchKernelGGL(k_mse_final, dim3(1), dim3(64), 0, as_stream(stream), partials, (int)g, loss);
     RHO_LAUNCH_CHECK();
     return 0;
