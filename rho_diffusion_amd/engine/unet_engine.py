@@ -187,6 +187,9 @@ class _StemAsGemm(_ConvW):
     def _source(self) -> Tensor:
         return self.weight.detach().reshape(self.cout, self.cin, 1, 1, 1).contiguous()
 
+    def enable_dgrad(self) -> None:
+        """A forward-only re-reading of the parameter: no data-gradient layout (the stem has no data gradient at all)."""
+
 
 class _HeadAsGemm(_ConvW):
     """Head conv with cout == 1 viewed as a 1x1x1 conv cin -> taps (rows = taps, padded to 32 output channels) whose
@@ -224,6 +227,12 @@ class _HeadAsGemm(_ConvW):
 
     def _bias_source(self) -> Tensor:
         return torch.zeros(32, dtype=torch.float32, device=self.weight.device)
+
+    def enable_dgrad(self) -> None:
+        """A forward-only re-reading of the parameter ([1, C, taps] read as 32 rows x C): the generic data-gradient preparation
+        would index the parameter with this geometry - 32 * C elements of a tensor that holds 27 * C (an out-of-bounds read that
+        faulted once the parameter sat at the end of its allocation, round 4).  The head's data gradient has weights of its own
+        (_HeadDgradW) or runs on the plain 3x3x3 form."""
 
 
 class _HeadDgradW:
