@@ -107,10 +107,15 @@ int rho_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr,
  *   h = w0 pe + b0;   emb = w2 silu(h) + b2 (+ cond[b, :])
  * t is int64[B]; when t_scalar_dev != NULL every b uses *t_scalar_dev (int32[1], device) instead (graph-replayable sampling
  * step).  pe_out [B, dim] / h_out [B, edim] (optional) keep what the backward needs.  w0 == NULL: sinusoid only into pe_out
- * (the registry layer SinusoidalPositionEmbedding, common.py:46-80). */
+ * (the registry layer SinusoidalPositionEmbedding, common.py:46-80).  act (ABI 7): the activation between the two linears, an
+ * ACTIVATION CODE - 0 identity, 1 SiLU, 2 ReLU, 3 GELU (erf), 4 Tanh, 5 Sigmoid, 6 ELU(1) - the elementwise, parameter-free entries
+ * of the reference's activation registry (registry.py:162-170, resolved at unet_v2.py:518-519).  The same codes are what the `pre_silu`
+ * argument of rho_gn_apply / rho_gn_bwd_reduce / rho_gn_bwd_apply and the `act_in` / `act_out` arguments of rho_linear / rho_linear_bwd
+ * take (0 / 1 keep their old meaning); the conv loaders (rho_conv_desc.pre_silu, gnb_silu) and rho_head_conv3d know 0 / 1 only - a
+ * network with another activation materialises its activated conv inputs with rho_gn_apply. */
 int rho_timestep_embed(const float* omega, const int64_t* t, const int32_t* t_scalar_dev, const float* w0, const float* b0,
                        const float* w2, const float* b2, const float* cond, float* pe_out, float* h_out, float* emb_out,
-                       int64_t batch, int64_t dim, int64_t edim, void* stream);
+                       int64_t batch, int64_t dim, int64_t edim, int act, void* stream);
 
 /* MultiEmbeddings.forward (models/conditioning.py:115-139): out[b, :] = sum over keys i of tables[i][j, :] with j the position
  * of y[b, i] in that key's value list (exact float equality, conditioning.py:132).  y float32 [B, nkeys] with row stride

@@ -118,26 +118,39 @@ def avg_pool(dims: int, x: Tensor) -> Tensor:
     return {1: F.avg_pool1d, 2: F.avg_pool2d}[dims](x, 2, 2)
 
 
+# the elementwise, parameter-free activations of the reference's registry (rho_diffusion/registry.py:162-170; the `activation`
+# argument of UNet / ResBlock, unet_v2.py:201,493,518-519), as torch evaluates the nn modules of the same names with default arguments
+ACTIVATIONS = {"SiLU": F.silu, "ReLU": F.relu, "GELU": F.gelu, "Tanh": torch.tanh, "Sigmoid": torch.sigmoid, "ELU": F.elu}
+
+
+def _act(cfg_or_name) -> "callable":
+    name = cfg_or_name if isinstance(cfg_or_name, str) else (cfg_or_name or {}).get("activation", "SiLU")
+    if not isinstance(name, str):
+        name = type(name).__name__
+    return ACTIVATIONS[name]
+
+
 def resblock(dims: int, x: Tensor, emb: Tensor, sd: Dict[str, Tensor], p: str,
-             use_scale_shift_norm: bool, updown: Optional[str] = None) -> Tensor:
+             use_scale_shift_norm: bool, updown: Optional[str] = None, act=F.silu) -> Tensor:
     """rho_diffusion/models/unet_v2.py:273-293 (ResBlock._forward, dropout 0).  updown = "up" / "down": the activated input and
-    the skip input are resampled before the first conv (:277-281; Upsample / Downsample without conv, :221-224)."""
-    h = F.silu(group_norm32(x, sd[p + "in_layers.0.weight"], sd[p + "in_layers.0.bias"]))
+    the skip input are resampled before the first conv (:277-281; Upsample / Downsample without conv, :221-224).  ``act``: the
+    activation the block was built with (:201,214,230,238)."""
+    h = act(group_norm32(x, sd[p + "in_layers.0.weight"], sd[p + "in_layers.0.bias"]))
     if updown is not None:
         rs = (lambda v: upsample(dims, v)) if updown == "up" else (lambda v: avg_pool(dims, v))
         h, x = rs(h), rs(x)
     h = conv_nd(dims, h, sd[p + "in_layers.2.weight"], sd[p + "in_layers.2.bias"], padding=1)
-    emb_out = F.linear(F.silu(emb), sd[p + "emb_layers.1.weight"], sd[p + "emb_layers.1.bias"]).type(h.dtype)
+    emb_out = F.linear(act(emb), sd[p + "emb_layers.1.weight"], sd[p + "emb_layers.1.bias"]).type(h.dtype)
     while emb_out.dim() < h.dim():
         emb_out = emb_out[..., None]
     if use_scale_shift_norm:
         scale, shift = torch.chunk(emb_out, 2, dim=1)
         h = group_norm32(h, sd[p + "out_layers.0.weight"], sd[p + "out_layers.0.bias"]) * (1 + scale) + shift
-        h = conv_nd(dims, F.silu(h), sd[p + "out_layers.3.weight"], sd[p + "out_layers.3.bias"], padding=1)
+        h = conv_nd(dims, act(h), sd[p + "out_layers.3.weight"], sd[p + "out_layers.3.bias"], padding=1)
     else:
         h = h + emb_out
         h = group_norm32(h, sd[p + "out_layers.0.weight"], sd[p + "out_layers.0.bias"])
-        h = conv_nd(dims, F.silu(h), sd[p + "out_layers.3.weight"], sd[p + "out_layers.3.bias"], padding=1)
+        h = conv_nd(dims, act(h), sd[p + "out_layers.3.weight"], sd[p + "out_layers.3.bias"], padding=1)
     if (p + "skip_connection.weight") in sd:
         w = sd[p + "skip_connection.weight"]
         pad = 1 if w.shape[-1] == 3 else 0
@@ -240,14 +253,15 @@ def unet_structure(cfg: dict) -> dict:
 def _run_layers(dims, layers, h, emb, sd, cfg):
     ssn = bool(cfg.get("use_scale_shift_norm", False))
     new_order = bool(cfg.get("use_new_attention_order", False))
+    act = _act(cfg)
     for layer in layers:
         kind, p = layer[0], layer[1]
         if kind == "conv":
             h = conv_nd(dims, h, sd[p + "weight"], sd[p + "bias"], padding=1)
         elif kind == "res":
-            h = resblock(dims, h, emb, sd, p, ssn)
+            h = resblock(dims, h, emb, sd, p, ssn, act=act)
         elif kind in ("res_up", "res_down"):
-            h = resblock(dims, h, emb, sd, p, ssn, updown=kind[4:])
+            h = resblock(dims, h, emb, sd, p, ssn, updown=kind[4:], act=act)
         elif kind == "pool":
             h = avg_pool(dims, h)
         elif kind == "up_only":
@@ -270,7 +284,7 @@ def unet_embedding(sd, cfg, timesteps: Tensor, y: Optional[Tensor] = None,
     assert (y is not None) == (num_classes is not None)
     e = sinusoidal_embedding(timesteps, mc)
     e = F.linear(e, sd["time_embed.0.weight"], sd["time_embed.0.bias"])
-    e = F.linear(F.silu(e), sd["time_embed.2.weight"], sd["time_embed.2.bias"])
+    e = F.linear(_act(cfg)(e), sd["time_embed.2.weight"], sd["time_embed.2.bias"])
     if num_classes is not None:
         if y.dim() == 2 and y.shape == e.shape:
             e = e + y
@@ -295,7 +309,7 @@ def unet_forward(sd: Dict[str, Tensor], cfg: dict, x: Tensor, timesteps: Tensor,
         h = torch.cat([h, hs.pop()], dim=1)
         h = _run_layers(dims, layers, h, emb, sd, cfg)
     h = group_norm32(h, sd["out.0.weight"], sd["out.0.bias"])
-    return conv_nd(dims, F.silu(h), sd["out.2.weight"], sd["out.2.bias"], padding=1)
+    return conv_nd(dims, _act(cfg)(h), sd["out.2.weight"], sd["out.2.bias"], padding=1)
 
 
 # --------------------------------------------------------------------------- DDPM

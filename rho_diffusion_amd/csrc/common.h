@@ -42,6 +42,32 @@ __device__ __forceinline__ float dsilu_f(float u) {
     return s * (1.0f + u * (1.0f - s));
 }
 
+// Activation codes of the C ABI wherever an `act` / `pre_silu` / `act_in` flag appears: 0 identity, 1 SiLU (each kernel keeps its own
+// SiLU expression - the conv loaders and the GroupNorm passes share silu_f / dsilu_f above), and the registry's other elementwise,
+// parameter-free activations (rho_diffusion/registry.py:162-170): 2 ReLU, 3 GELU (erf form = nn.GELU() default), 4 Tanh, 5 Sigmoid,
+// 6 ELU (alpha = 1).  These run in the HBM-bound passes only (k_gn_apply / k_gn_bwd_*, the embedding linears): a UNetv2 built with one
+// of them materialises its activated conv inputs, the conv loaders never see them.
+__device__ __forceinline__ float act_other_f(float u, int act) {
+    switch (act) {
+        case 2: return u > 0.0f ? u : 0.0f;
+        case 3: return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f));
+        case 4: return tanhf(u);
+        case 5: return 1.0f / (1.0f + expf(-u));
+        case 6: return u > 0.0f ? u : expm1f(u);
+        default: return u;
+    }
+}
+__device__ __forceinline__ float dact_other_f(float u, int act) {
+    switch (act) {
+        case 2: return u > 0.0f ? 1.0f : 0.0f;
+        case 3: return 0.5f * (1.0f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * expf(-0.5f * u * u);
+        case 4: { const float t = tanhf(u); return 1.0f - t * t; }
+        case 5: { const float s = 1.0f / (1.0f + expf(-u)); return s * (1.0f - s); }
+        case 6: return u > 0.0f ? 1.0f : expf(u);
+        default: return 1.0f;
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ x, con
             const int k = lane + 64 * j;
             if (k < in_dim) {
                 float xv = x[(int64_t)b * in_dim + k];
-                if (act_in) xv = xv / (1.0f + expf(-xv));
+                if (act_in) xv = act_in == 1 ? xv / (1.0f + expf(-xv)) : act_other_f(xv, act_in);
                 acc = fmaf(xv, wr[j], acc);
             }
         }
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ x, con
         if (lane == 0) {
             float r = acc + bo;
             if (add) r += add[(int64_t)b * out_dim + o];
-            if (act_out) r = r / (1.0f + expf(-r));
+            if (act_out) r = act_out == 1 ? r / (1.0f + expf(-r)) : act_other_f(r, act_out);
             out[(int64_t)b * out_dim + o] = r;
         }
     }
@@ -1068,7 +1068,7 @@ __global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ 
     float acc = 0.0f, accb = 0.0f;
     for (int b = 0; b < batch; ++b) {
         float xv = x[(int64_t)b * in_dim + k];
-        if (act_in) xv = xv / (1.0f + expf(-xv));
+        if (act_in) xv = act_in == 1 ? xv / (1.0f + expf(-xv)) : act_other_f(xv, act_in);
         const float g = dout[(int64_t)b * dstride + o];
         acc = fmaf(g, xv, acc);
         accb += g;
@@ -1090,10 +1090,12 @@ __global__ __launch_bounds__(256) void k_linear_bwd_x(const float* __restrict__ 
     float acc = 0.0f;
 #pragma unroll 8
     for (int o = o0; o < o1; ++o) acc = fmaf(dout[(int64_t)b * dstride + o], w[(int64_t)o * in_dim + k], acc);
-    if (act_in) {
+    if (act_in == 1) {
         const float u = x[i];
         const float s = 1.0f / (1.0f + expf(-u));
         acc *= s * (1.0f + u * (1.0f - s));
+    } else if (act_in) {
+        acc *= dact_other_f(x[i], act_in);
     }
     atomicAdd(dx + i, acc);
 }
@@ -1108,10 +1110,12 @@ __global__ __launch_bounds__(256) void k_linear_bwd_x_det(const float* __restric
     float acc = 0.0f;
 #pragma unroll 8
     for (int o = 0; o < out_dim; ++o) acc = fmaf(dout[(int64_t)b * dstride + o], w[(int64_t)o * in_dim + k], acc);
-    if (act_in) {
+    if (act_in == 1) {
         const float u = x[i];
         const float s = 1.0f / (1.0f + expf(-u));
         acc *= s * (1.0f + u * (1.0f - s));
+    } else if (act_in) {
+        acc *= dact_other_f(x[i], act_in);
     }
     dx[i] = acc_dx ? dx[i] + acc : acc;
 }

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void k_timestep_embed(const float* __restrict_
                                                         const float* __restrict__ b0, const float* __restrict__ w2,
                                                         const float* __restrict__ b2, const float* __restrict__ cond,
                                                         float* __restrict__ pe_out, float* __restrict__ h_out,
-                                                        float* __restrict__ emb_out, int dim, int edim) {
+                                                        float* __restrict__ emb_out, int dim, int edim, int act) {
     extern __shared__ float sm[];
     float* const pe = sm;               // [dim]
     float* const hs = sm + dim;         // [edim]  silu(h)
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_timestep_embed(const float* __restrict_
         if (lane == 0) {
             const float h = acc + b0[o];
             if (h_out != nullptr) h_out[(int64_t)b * edim + o] = h;
-            hs[o] = h / (1.0f + expf(-h));
+            hs[o] = act == 1 ? h / (1.0f + expf(-h)) : act_other_f(h, act);
         }
     }
     __syncthreads();
@@ -62,14 +62,14 @@ __global__ __launch_bounds__(256) void k_timestep_embed(const float* __restrict_
 
 extern "C" int rho_timestep_embed(const float* omega, const int64_t* t, const int32_t* t_scalar_dev, const float* w0,
                                   const float* b0, const float* w2, const float* b2, const float* cond, float* pe_out,
-                                  float* h_out, float* emb_out, int64_t batch, int64_t dim, int64_t edim, void* stream) {
+                                  float* h_out, float* emb_out, int64_t batch, int64_t dim, int64_t edim, int act, void* stream) {
     if (!omega || (!t && !t_scalar_dev) || batch <= 0 || dim <= 0 || (dim & 1)) return RHO_E_ARG;
     if (w0 != nullptr && (!b0 || !w2 || !b2 || !emb_out || edim <= 0)) return RHO_E_ARG;
     if (w0 == nullptr && !pe_out) return RHO_E_ARG;
     if (dim > 8192 || edim > 16384) return RHO_E_SHAPE;
     const size_t lds = (size_t)(dim + (w0 ? edim : 0)) * sizeof(float);
     hipLaunchKernelGGL(k_timestep_embed, dim3((unsigned)batch), dim3(256), lds, as_stream(stream), omega, t, t_scalar_dev, w0, b0, w2,
-                       b2, cond, pe_out, h_out, emb_out, (int)dim, (int)edim);
+                       b2, cond, pe_out, h_out, emb_out, (int)dim, (int)edim, act);
     RHO_LAUNCH_CHECK();
     return 0;
 }

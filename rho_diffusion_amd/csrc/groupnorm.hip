@@ -360,9 +360,12 @@ __global__ __launch_bounds__(256) void k_gn_bwd_reduce(const T* __restrict__ g, 
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float gq = gv[j], gr = gw[j];
-                if (pre_silu) {
+                if (pre_silu == 1) {
                     gq *= dsilu_f(fmaf(av[j], xv[j], bv[j]));
                     gr *= dsilu_f(fmaf(av[j], xw[j], bv[j]));
+                } else if (pre_silu) {
+                    gq *= dact_other_f(fmaf(av[j], xv[j], bv[j]), pre_silu);
+                    gr *= dact_other_f(fmaf(av[j], xw[j], bv[j]), pre_silu);
                 }
                 r1[j] += gq + gr;
                 r2[j] = fmaf(gq, (xv[j] - mu[j]) * rs[j], fmaf(gr, (xw[j] - mu[j]) * rs[j], r2[j]));
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(256) void k_gn_bwd_reduce(const T* __restrict__ g, 
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float gq = gv[j];
-                if (pre_silu) gq *= dsilu_f(fmaf(av[j], xv[j], bv[j]));
+                if (pre_silu) gq *= (pre_silu == 1 ? dsilu_f(fmaf(av[j], xv[j], bv[j])) : dact_other_f(fmaf(av[j], xv[j], bv[j]), pre_silu));
                 r1[j] += gq;
                 r2[j] = fmaf(gq, (xv[j] - mu[j]) * rs[j], r2[j]);
             }
@@ -621,7 +624,7 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(const T* __restrict__ g, c
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float gq = gv[j];
-            if (pre_silu) gq *= dsilu_f(fmaf(av[j], xv[j], bv[j]));
+            if (pre_silu) gq *= (pre_silu == 1 ? dsilu_f(fmaf(av[j], xv[j], bv[j])) : dact_other_f(fmaf(av[j], xv[j], bv[j]), pre_silu));
             float r = fmaf(ca[j], gq, fmaf(cq[j], xv[j], cp[j]));
             // (the order of the separate passes: the residual's gradient joins the running sum first, rounded to the storage type as
             //  rho_add_inplace stores it, then this term)
@@ -698,7 +701,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const T* __restrict__ x1, int 
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float f = fmaf(av[j], xv[u][j], bv[j]);
-                xv[u][j] = pre_silu ? silu_f(f) : f;
+                xv[u][j] = pre_silu == 1 ? silu_f(f) : (pre_silu ? act_other_f(f, pre_silu) : f);
             }
             store_octet<T>(yp + (p + u * ppi) * C, xv[u]);
         }
@@ -709,7 +712,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const T* __restrict__ x1, int 
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float f = fmaf(av[j], xv[j], bv[j]);
-            xv[j] = pre_silu ? silu_f(f) : f;
+            xv[j] = pre_silu == 1 ? silu_f(f) : (pre_silu ? act_other_f(f, pre_silu) : f);
         }
         store_octet<T>(yp + p * C, xv);
     }

@@ -139,6 +139,11 @@ def adamw(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, beta1: float, b
 
 
 # ----------------------------------------------------------------------------- embeddings
+# activation codes of the C ABI (include/rho_hip.h, rho_timestep_embed): the elementwise, parameter-free entries of the reference's
+# activation registry (rho_diffusion/registry.py:162-170)
+ACT_CODES = {"Identity": 0, "SiLU": 1, "ReLU": 2, "GELU": 3, "Tanh": 4, "Sigmoid": 5, "ELU": 6}
+
+
 def sinusoid_frequencies(dim: int, wavelength: int = 10000, device=None) -> Tensor:
     """omega_i = wavelength^(2i / dim), i = 0 .. dim/2 - 1, float32: the denominators of the timestep sinusoid
     (models/common.py:38 evaluates this very expression; the kernel divides t by it)."""
@@ -151,8 +156,9 @@ def sinusoid_frequencies(dim: int, wavelength: int = 10000, device=None) -> Tens
 def timestep_embed(omega: Tensor, t: Optional[Tensor], batch: int, *, t_scalar_dev: Optional[Tensor] = None,
                    w0: Optional[Tensor] = None, b0: Optional[Tensor] = None, w2: Optional[Tensor] = None,
                    b2: Optional[Tensor] = None, cond: Optional[Tensor] = None, pe_out: Optional[Tensor] = None,
-                   h_out: Optional[Tensor] = None, emb_out: Optional[Tensor] = None):
-    """Sinusoid of any integer t (+ the time_embed MLP and the label-embedding add when w0 is given): rho_timestep_embed."""
+                   h_out: Optional[Tensor] = None, emb_out: Optional[Tensor] = None, act: int = 1):
+    """Sinusoid of any integer t (+ the time_embed MLP and the label-embedding add when w0 is given): rho_timestep_embed.
+    ``act``: activation code between the two linears (1 = SiLU, see ACT_CODES)."""
     _f32c(omega, "omega")
     dim = 2 * omega.numel()
     if t is not None and (t.dtype != torch.int64 or not t.is_cuda or not t.is_contiguous()):
@@ -163,7 +169,7 @@ def timestep_embed(omega: Tensor, t: Optional[Tensor], batch: int, *, t_scalar_d
     if w0 is not None and emb_out is None:
         emb_out = torch.empty(batch, edim, dtype=torch.float32, device=omega.device)
     check(hip.lib().rho_timestep_embed(ptr(omega), ptr(t), ptr(t_scalar_dev), ptr(w0), ptr(b0), ptr(w2), ptr(b2), ptr(cond),
-                                       ptr(pe_out), ptr(h_out), ptr(emb_out), batch, dim, edim, stream()), "rho_timestep_embed")
+                                       ptr(pe_out), ptr(h_out), ptr(emb_out), batch, dim, edim, int(act), stream()), "rho_timestep_embed")
     return pe_out if w0 is None else emb_out
 
 

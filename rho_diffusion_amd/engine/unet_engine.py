@@ -302,6 +302,8 @@ class UNetEngine:
         self.dims = model.dims
         self.mc = model.model_channels
         self.ssn = bool(model.use_scale_shift_norm)
+        # activation code of the network (1 = SiLU: fused into the conv loaders; anything else runs in the materialising passes)
+        self.act = int(getattr(model, "act_code", 1))
         self._plans: Dict[tuple, "_Plan"] = {}
         self._convs: List[_ConvW] = []
         self._aux_weights: list = []          # prepared layouts that are not convolutions of their own (see _head_dgrad)
@@ -628,7 +630,7 @@ class _Plan:
         # timestep pointer changes per call); sin_in / emb_h are kept for the backward
         self.cond_idx = buf(B, 16, dtype=torch.int32) if has_y else None
         if eng.film_total:
-            op_linear(self.emb, eng.film_w, eng.film_b, None, self.film, True, False)
+            op_linear(self.emb, eng.film_w, eng.film_b, None, self.film, eng.act, False)
 
         # ---- helpers that append launches
         def gn(x1, x2, norm, film_blk=None):
@@ -695,7 +697,11 @@ class _Plan:
             # into a recycled buffer (the recompute path of bias_and_wgrad), the forward conv applies GroupNorm + FiLM + SiLU in its
             # loader or, for the wide layers, from a scratch copy that the next conv overwrites
             keep_act = self.train and self.materialize_act and not ckpt
-            if pre is not None and up_hw == (0, 0) and (keep_act or wide_1x1 or wide_3x3):
+            # (an activation other than SiLU exists in the materialising pass only: the conv loaders know identity and SiLU)
+            other_act = pre is not None and int(pre_silu) > 1
+            if other_act and up_hw != (0, 0):
+                raise hip.RhoHipError("internal: a normalised conv behind an upsample with a non-SiLU activation")
+            if pre is not None and up_hw == (0, 0) and (keep_act or wide_1x1 or wide_3x3 or other_act):
                 # training: the activated input act(a*x+b) is needed twice (this conv, its weight gradient) and the conv
                 # loader would recompute it 2.3x (halo) per cout tile: materialise it once (one HBM-rate pass, kept for
                 # backward: +1 activation-sized buffer per normalised conv, 38 GB at c3) and feed both from it
@@ -805,7 +811,7 @@ class _Plan:
             from ..models.unet_v2 import Upsample as _Up
             mode = "up" if isinstance(blk.h_upd, _Up) else "avg"
             g1 = gn(h1, h2, blk.in_layers[0])
-            hh = resample(activated(h1, h2, g1, True), mode)
+            hh = resample(activated(h1, h2, g1, eng.act), mode)
             x1p = resample(h1, mode)
             x2p = resample(h2, mode) if h2 is not None else None
             radd = None if blk.use_scale_shift_norm else eng._film_off[id(blk)]
@@ -816,7 +822,7 @@ class _Plan:
                 sk = x1p
             else:
                 sk, _ = conv(x1p, x2p, eng._conv(blk.skip_connection))
-            out, _ = conv(t1, None, eng._conv(blk.out_layers[3]), pre=g2, pre_silu=True, res=sk, ckpt=bool(blk.use_checkpoint))
+            out, _ = conv(t1, None, eng._conv(blk.out_layers[3]), pre=g2, pre_silu=eng.act, res=sk, ckpt=bool(blk.use_checkpoint))
             return out
 
         def resblock(blk, h1, h2):
@@ -825,7 +831,7 @@ class _Plan:
             g1 = gn(h1, h2, blk.in_layers[0])
             radd = None if blk.use_scale_shift_norm else eng._film_off[id(blk)]
             ck = bool(blk.use_checkpoint)
-            t1, _ = conv(h1, h2, eng._conv(blk.in_layers[2]), pre=g1, pre_silu=True, res_add_off=radd, ckpt=ck)
+            t1, _ = conv(h1, h2, eng._conv(blk.in_layers[2]), pre=g1, pre_silu=eng.act, res_add_off=radd, ckpt=ck)
             g2 = gn(t1, None, blk.out_layers[0], film_blk=blk if blk.use_scale_shift_norm else None)
             if isinstance(blk.skip_connection, nn.Identity):
                 assert h2 is None
@@ -850,7 +856,7 @@ class _Plan:
                             self.nodes.append(dict(k="conv", cw=skw, x1=h1, x2=h2, y=skd, y2=None, stride_hw=(1, 1), up_hw=(0, 0), pre=None,
                                                    pre_silu=False, res=None, res_add_off=None, stem=False, out_dims=(N_, D_, H_, W_),
                                                    xact=None, phased=False, s2=False))
-                        out, _ = conv(t1, None, ocw, pre=g2, pre_silu=True, ckpt=ck, fold_skip=fs, node_res=skd)
+                        out, _ = conv(t1, None, ocw, pre=g2, pre_silu=eng.act, ckpt=ck, fold_skip=fs, node_res=skd)
                         # the launch's work = the 27-tap conv + the folded 1x1x1 (both algorithmic FLOPs of the reference's
                         # formulation); the 1x1x1 share is also reported on its own (bench: roofline.folded_conv1_flops_per_step)
                         fl = 2.0 * (t1.numel() // t1.shape[-1]) * ocw.cout * skw.cin
@@ -860,7 +866,7 @@ class _Plan:
                         self.info[-1]["bytes"] += float(esz) * (t1.numel() // t1.shape[-1]) * skw.cin
                         return out
                 sk, _ = conv(h1, h2, skw)
-            out, _ = conv(t1, None, eng._conv(blk.out_layers[3]), pre=g2, pre_silu=True, res=sk, ckpt=ck)
+            out, _ = conv(t1, None, eng._conv(blk.out_layers[3]), pre=g2, pre_silu=eng.act, res=sk, ckpt=ck)
             return out
 
         def attention(blk, xin):
@@ -959,14 +965,16 @@ class _Plan:
             hg = eng._conv_as_gemm(m.out[2], _HeadAsGemm)
             y2 = buf(B, 1, D * H * W, dtype=torch.float32)
             npos = B * D * H * W
-            if train:
-                # the activated input is kept (the head's weight gradient contracts it with the im2col of dpred)
-                xact = buf(B, D, H, W, h.shape[-1])
-                ga0 = (ptr(h), h.shape[-1], None, 0, dtc, B, D * H * W, ptr(g["a"]), ptr(g["b"]), 1, ptr(xact))
+            if train or eng.act != 1:
+                # training: the activated input is kept (the head's weight gradient contracts it with the im2col of dpred);
+                # a non-SiLU activation: applied by the materialising pass (the head kernel's own prologue knows SiLU only)
+                xact = (buf if train else scratch)(B, D, H, W, h.shape[-1])
+                ga0 = (ptr(h), h.shape[-1], None, 0, dtc, B, D * H * W, ptr(g["a"]), ptr(g["b"]), eng.act, ptr(xact))
                 self.ops.append(lambda s, a=ga0: L.rho_gn_apply(*a, s))
                 self.info.append(dict(kind="gn_apply", flops=0.0, bytes=2.0 * esz * xact.numel()))
                 ga = (ptr(xact), None, None, 0, ptr(hg.w), ptr(m.out[2].bias), ptr(y2), B, D, H, W, h.shape[-1])
-                self.nodes.append(dict(k="head_direct", x=h, pre=g, xact=xact, cw=head, y2=y2, out_dims=(B, D, H, W)))
+                if train:
+                    self.nodes.append(dict(k="head_direct", x=h, pre=g, xact=xact, cw=head, y2=y2, out_dims=(B, D, H, W)))
             else:
                 ga = (ptr(h), ptr(g["a"]), ptr(g["b"]), 1, ptr(hg.w), ptr(m.out[2].bias), ptr(y2), B, D, H, W, h.shape[-1])
             self.ops.append(lambda s, a=ga: L.rho_head_conv3d(*a, s))
@@ -974,13 +982,13 @@ class _Plan:
             self.info.append(dict(kind="head", flops=2.0 * npos * h.shape[-1] * 27, bytes=float(esz) * npos * h.shape[-1] + 4.0 * npos))
         elif gemm_ends and head.taps > 1 and head.cout == 1:
             hg = eng._conv_as_gemm(m.out[2], _HeadAsGemm)
-            tt, _ = conv(h, None, hg, pre=g, pre_silu=True, want_stats=False)          # [B, D, H, W, 32]: one column per tap
+            tt, _ = conv(h, None, hg, pre=g, pre_silu=eng.act, want_stats=False)          # [B, D, H, W, 32]: one column per tap
             y2 = buf(B, 1, D * H * W, dtype=torch.float32)
             ga = (ptr(tt), dtc, B, D, H, W) + hg.kernel3 + (hg.coutp, ptr(m.out[2].bias), ptr(y2))
             self.ops.append(lambda s, a=ga: L.rho_tap_gather_sum(*a, s))
             self.info.append(dict(kind="tap_sum", flops=0.0, bytes=2.0 * tt.numel() + 4.0 * y2.numel()))
         else:
-            _, y2 = conv(h, None, head, pre=g, pre_silu=True, split=0, y2_dtype=torch.float32)
+            _, y2 = conv(h, None, head, pre=g, pre_silu=eng.act, split=0, y2_dtype=torch.float32)
         self.out = y2.view(B, m.out_channels, *xshape[2:])
 
         self.bwd: List[Callable[[int], int]] = []
@@ -1378,7 +1386,7 @@ class _Plan:
                 dact = pool.get(tshape, dt)       # gradient of the activated / upsampled tensor
                 d = ops.make_conv_desc(dY, None, cw.wd, cw.zero_bias, split=cin, y=dact, y2=None, **common)
                 fused = None
-                if pre is not None and self.fuse_gn_bwd > 0 and cin >= self.fuse_gn_bwd:
+                if pre is not None and self.fuse_gn_bwd > 0 and cin >= self.fuse_gn_bwd and int(node["pre_silu"]) <= 1:
                     # the norm's backward reductions ride in this launch's epilogue where a tile lies in one sample
                     tiles = int(L.rho_conv_stats_tiles(C.byref(d)))
                     if tiles > 0:
@@ -1481,7 +1489,7 @@ class _Plan:
             fin_add(kind=0, off=off_b + 13, param=hcw.bias_param, rs=None, cout=1, cin=1, coutp=1, cinb=1, k=(1, 1, 1))
             fin["params"] += [hcw.weight, hcw.bias_param]
             fin["bytes"] += 4 * hcw.weight.numel()
-            gn_backward(head["pre"], True, head["x"], None, dact)
+            gn_backward(head["pre"], eng.act, head["x"], None, dact)
             pool.put(dact)
             self.bwd_marks.append((len(bw), [head["pre"]["norm"].weight, head["pre"]["norm"].bias]))
         else:
@@ -1624,7 +1632,7 @@ class _Plan:
             emb_params += [lin.weight, lin.bias]
         te0, te2 = m.time_embed[0], m.time_embed[2]
         emit(lambda s: L.rho_linear_bwd(ptr(self.demb), 0, ptr(self.emb_h), ptr(te2.weight), pgrad(te2.weight), pgrad(te2.bias),
-                                        ptr(self.demb_h), B, e, e, 1, 1, 0, s), "linear_bwd")
+                                        ptr(self.demb_h), B, e, e, eng.act, 1, 0, s), "linear_bwd")
         emit(lambda s: L.rho_linear_bwd(ptr(self.demb_h), 0, ptr(self.sin_in), ptr(te0.weight), pgrad(te0.weight), pgrad(te0.bias),
                                         None, B, eng.mc, e, 0, 1, 0, s), "linear_bwd")
         emb_params += [te2.weight, te2.bias, te0.weight, te0.bias]
@@ -1692,7 +1700,7 @@ class _Plan:
             tptr, tsptr = ptr(self.t_in), None
         check(self.L.rho_timestep_embed(ptr(eng.omega()), tptr, tsptr, ptr(te0.weight), ptr(te0.bias), ptr(te2.weight), ptr(te2.bias),
                                         ptr(self.cond), ptr(self.sin_in), ptr(self.emb_h), ptr(self.emb), self.B, eng.mc,
-                                        self.emb.shape[1], hip.stream()), "rho_timestep_embed")
+                                        self.emb.shape[1], eng.act, hip.stream()), "rho_timestep_embed")
         s = hip.stream()
         for op in self.ops:
             rc = op(s)

@@ -80,7 +80,7 @@ SIGNATURES = {
     "rho_set_deterministic": (c_int, [c_int]),
     "rho_get_deterministic": (c_int, []),
     "rho_adamw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int32, c_void_p]),
-    "rho_timestep_embed": (c_int, [c_void_p] * 11 + [c_int64, c_int64, c_int64, c_void_p]),
+    "rho_timestep_embed": (c_int, [c_void_p] * 11 + [c_int64, c_int64, c_int64, c_int, c_void_p]),
     "rho_multi_embed": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                 c_void_p]),
     "rho_multi_embed_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),

@@ -75,6 +75,27 @@ class Downsample(nn.Module):
         return self.op(x)
 
 
+def activation_code(activation: nn.Module) -> int:
+    """Activation code of the HIP engine (``engine.ops.ACT_CODES``) for an activation module of the reference's registry
+    (rho_diffusion/registry.py:162-170, resolved at unet_v2.py:518-519).  The elementwise, parameter-free ones are built: SiLU (fused
+    into the conv loaders), ReLU, GELU (erf form), Tanh, Sigmoid, ELU (alpha = 1) - the latter five run in the materialising GroupNorm
+    passes.  PReLU carries a learnable parameter shared by every use of the one module instance, Softmax / LogSoftmax are not
+    elementwise: refused, naming the line."""
+    from ..engine.ops import ACT_CODES
+    name = type(activation).__name__
+    ok = name in ACT_CODES and name != "Identity"
+    if name == "GELU" and getattr(activation, "approximate", "none") != "none":
+        ok = False
+    if name == "ELU" and float(getattr(activation, "alpha", 1.0)) != 1.0:
+        ok = False
+    if not ok:
+        raise NotImplementedError(
+            f"activation={name}: the reference resolves it through the registry (rho_diffusion/models/unet_v2.py:518-519, "
+            "registry.py:162-170); the HIP engine builds SiLU, ReLU, GELU (erf), Tanh, Sigmoid and ELU (alpha = 1) for UNetv2 - not "
+            "PReLU (a learnable parameter shared by all uses of the module), Softmax / LogSoftmax (not elementwise) or variants")
+    return ACT_CODES[name]
+
+
 class ResBlock(TimestepBlock):
     """GN-SiLU-conv, FiLM (scale-shift) or additive embedding, GN-SiLU-conv(zero-init), skip
     (unet_v2.py:172-293).  ``up`` / ``down`` (resblock_updown): the activated input and the skip input are resampled
@@ -88,11 +109,7 @@ class ResBlock(TimestepBlock):
             raise NotImplementedError(
                 f"dropout={dropout}: nn.Dropout(p=dropout) in ResBlock.out_layers (reference rho_diffusion/models/unet_v2.py:239) is not "
                 "built in the HIP engine - every shipped configuration (examples/*.json) trains with dropout 0")
-        if not isinstance(activation, nn.SiLU):
-            raise NotImplementedError(
-                f"activation={type(activation).__name__}: the reference resolves it through the registry (rho_diffusion/models/"
-                "unet_v2.py:518-519, registry.py:162-170); the HIP engine fuses SiLU into its conv loaders and GroupNorm backward and "
-                "has no other activation for UNetv2 (the legacy UNet, models/unet.py, runs ReLU / GELU)")
+        self.act_code = activation_code(activation)
         self.channels = channels
         self.emb_channels = emb_channels
         self.dropout = dropout
@@ -194,6 +211,7 @@ class UNet(nn.Module):
         embedding_dim = model_channels * 4
         if isinstance(activation, str):
             activation = registry.get("activations", activation)()
+        self.act_code = activation_code(activation)
 
         self.time_embed = nn.Sequential(nn.Linear(model_channels, embedding_dim), activation,
                                         nn.Linear(embedding_dim, embedding_dim))

@@ -70,3 +70,13 @@ V1_CASES = {
     "v1_plain": (dict(block_type="UNetBlock2d", input_channels=1, down_channels=[32, 64], up_channels=[64, 32],
                       time_embedding_dim=16, activation="SiLU", residual=False), (3, 1, 8, 8)),
 }
+
+
+# ---- UNetv2 built with the registry's other elementwise activations (rho_diffusion/registry.py:162-170, unet_v2.py:518-519): g17_activations.npz
+ACT_CASES = {
+    "relu3d": (dict(_tiny, dims=3, data_shape=[4, 8, 8], activation="ReLU"), (2, 1, 4, 8, 8), None),
+    "gelu2d": (dict(_tiny, dims=2, data_shape=[16, 16], activation="GELU"), (2, 1, 16, 16), None),
+    "tanh2d_add": (dict(_tiny, dims=2, data_shape=[16, 16], activation="Tanh", use_scale_shift_norm=False), (2, 1, 16, 16), None),
+    "sigmoid1d": (dict(_tiny, dims=1, data_shape=[32], activation="Sigmoid"), (2, 1, 32), None),
+    "elu3d_updown": (dict(_tiny, dims=3, data_shape=[4, 8, 8], activation="ELU", resblock_updown=True), (2, 1, 4, 8, 8), None),
+}

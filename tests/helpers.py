@@ -6,7 +6,8 @@ import os
 import numpy as np
 import torch
 
-from golden_cfg import DEEP_GALAXY_SPACE, PARAM_SPACE, UNET_CASES, UPDOWN_CASES, V1_CASES, WIDE_CASES, galaxy_labels  # noqa: F401  (re-exported)
+from golden_cfg import (ACT_CASES, DEEP_GALAXY_SPACE, PARAM_SPACE, UNET_CASES, UPDOWN_CASES, V1_CASES, WIDE_CASES,  # noqa: F401  (re-exported)
+                        galaxy_labels)
 from detdata import det_normal, det_state_dict, det_uniform  # noqa: F401
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")

@@ -7,8 +7,9 @@ import pytest
 import torch
 from torch import nn
 
-from helpers import (PARAM_SPACE, UNET_CASES, case_inputs, det_normal, det_state_dict, det_uniform, golden_template, load_golden,
-                     rel_l2)
+from helpers import (ACT_CASES, PARAM_SPACE, UNET_CASES, case_inputs, cosine, det_normal, det_state_dict, det_uniform, golden_template,
+                     grad_digest_of, load_golden, rel_l2)
+from oracle import ref_torch as R
 from gpu_util import DEV
 
 pytestmark = pytest.mark.gpu
@@ -184,3 +185,51 @@ def test_plan_key_follows_use_checkpoint_and_switches(monkeypatch):
     assert eng._last_train_plan is not p0 and eng._last_train_plan is not p1
     eng.drop_plans(train_only=True)
     assert eng._last_train_plan is None and all(not k[2] for k in eng._plans)
+
+
+# ----------------------------------------------------------------------------- UNetv2 with the registry's other activations
+@pytest.mark.parametrize("case", list(ACT_CASES.keys()))
+def test_unets_with_other_activations_forward_and_gradients_vs_reference_golden(case):
+    """`activation="ReLU" | "GELU" | "Tanh" | "Sigmoid" | "ELU"` (reference: resolved through the registry, unet_v2.py:518-519,
+    registry.py:162-170; used in time_embed, every ResBlock and the head, :214,230,238,523,681).  The HIP engine applies them in the
+    materialising GroupNorm passes (rho_gn_apply / rho_gn_bwd_* with an activation code) and in the embedding linears; the conv loaders
+    stay SiLU-only.  State-dict layout, fp32 forward 1e-4 + gradient norms 2e-3, bf16 forward 3e-2 + per-parameter gradient cosine
+    >= 0.99 against the oracle (pinned to the reference class by g17), inference plans too (the same forward without autograd)."""
+    import math
+    from rho_diffusion_amd.autograd import mse_loss
+    from rho_diffusion_amd.models import UNet
+    g = load_golden("g17_activations.npz")
+    kw, xshape, _ = ACT_CASES[case]
+    sd = det_state_dict(golden_template(g, case), case)
+    x = det_normal(xshape, case + "x")
+    t = torch.tensor([(37 * i + 11) % 1000 for i in range(xshape[0])])
+    gold = torch.from_numpy(g[f"{case}/pred"])
+    target = det_normal(tuple(gold.shape), case + "tgt")
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    torch.nn.functional.mse_loss(R.unet_forward(sdg, dict(kw), x, t), target).backward()
+    gtot = math.sqrt(sum(float(v.grad.double().norm()) ** 2 for v in sdg.values() if v.grad is not None))
+    for dtype in ("fp32", "bf16"):
+        model = UNet(**dict(kw, compute_dtype=dtype))
+        assert [f"{k}|{','.join(map(str, v.shape))}" for k, v in model.state_dict().items()] == [str(s_) for s_ in g[f"{case}/keys"]]
+        model.load_state_dict(sd)
+        model = model.to(DEV).eval()
+        with torch.no_grad():
+            p_inf = model(x.to(DEV), t.to(DEV))
+        assert rel_l2(p_inf, gold) < (1e-4 if dtype == "fp32" else 3e-2), (case, dtype, "inference", rel_l2(p_inf, gold))
+        model.train()
+        pred = model(x.to(DEV), t.to(DEV))
+        assert rel_l2(pred, gold) < (1e-4 if dtype == "fp32" else 3e-2), (case, dtype, rel_l2(pred, gold))
+        loss = mse_loss(pred, target.to(DEV))
+        assert abs(float(loss) - float(g[f"{case}/loss"])) < (1e-4 if dtype == "fp32" else 5e-2)
+        loss.backward()
+        bad = []
+        for name, p in model.named_parameters():
+            ref = g[f"{case}/grad/{name}"]
+            if dtype == "fp32":
+                if abs(grad_digest_of(p.grad)[0] - ref[0]) > 2e-3 * ref[0] + 1e-6:
+                    bad.append((name, grad_digest_of(p.grad)[0], ref[0]))
+            elif ref[0] >= 1e-5 * gtot and not (p.numel() <= 4 and name == "out.2.bias"):
+                c = cosine(p.grad, sdg[name].grad)
+                if c < 0.99 or abs(float(p.grad.double().norm()) - ref[0]) > 0.05 * ref[0]:
+                    bad.append((name, round(c, 4), float(p.grad.double().norm()) / ref[0]))
+        assert not bad, (dtype, bad[:6])

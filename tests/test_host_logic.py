@@ -176,7 +176,7 @@ def test_alias_makes_reference_imports_resolve_here():
         del sys.modules[k]
 
 
-def test_unetv2_refuses_dropout_and_foreign_activations_naming_the_reference_lines():
+def test_unetv2_refuses_dropout_and_unbuilt_activations_naming_the_reference_lines():
     """The two constructor arguments of the reference's UNetv2 that this engine does not build (VERDICT r3 missing #2): the refusal is
     loud, at construction, and says which reference lines it stands for."""
     from rho_diffusion_amd.models import UNet
@@ -184,9 +184,13 @@ def test_unetv2_refuses_dropout_and_foreign_activations_naming_the_reference_lin
               attention_resolutions=[], num_heads=2, dims=2)
     with pytest.raises(NotImplementedError, match=r"unet_v2\.py:239"):
         UNet(**kw, dropout=0.1)
+    for bad in ("PReLU", "Softmax", "LogSoftmax"):
+        with pytest.raises(NotImplementedError, match=r"unet_v2\.py:518-519"):
+            UNet(**kw, activation=bad)
     with pytest.raises(NotImplementedError, match=r"unet_v2\.py:518-519"):
-        UNet(**kw, activation="ReLU")
-    UNet(**kw, dropout=0.0, activation="SiLU")
+        UNet(**kw, activation=torch.nn.GELU(approximate="tanh"))
+    for good, code in (("SiLU", 1), ("ReLU", 2), ("GELU", 3), ("Tanh", 4), ("Sigmoid", 5), ("ELU", 6)):
+        assert UNet(**kw, dropout=0.0, activation=good).act_code == code
 
 
 def test_head_dgrad_weight_layout_is_the_mirrored_taps_as_contraction_form():

@@ -253,6 +253,30 @@ def test_g15_updown_and_pooled_unets(case):
     assert n > 20
 
 
+@pytest.mark.parametrize("case", ["relu3d", "gelu2d", "tanh2d_add", "sigmoid1d", "elu3d_updown"])
+def test_g17_unets_with_other_activations(case):
+    """UNetv2 built with the registry's other elementwise activations (registry.py:162-170, unet_v2.py:493,518-519): the oracle's
+    forward, loss and every parameter's gradient norm against the reference class (g17, minted by make_golden.py)."""
+    from helpers import ACT_CASES
+    g = load_golden("g17_activations.npz")
+    kw, xshape, _ = ACT_CASES[case]
+    x = det_normal(xshape, case + "x")
+    t = torch.tensor([(37 * i + 11) % 1000 for i in range(xshape[0])])
+    sd = {k: v.requires_grad_(True) for k, v in det_state_dict(golden_template(g, case), case).items()}
+    pred = R.unet_forward(sd, dict(kw), x, t)
+    assert rel_l2(pred, torch.from_numpy(g[f"{case}/pred"])) < TOL
+    loss = torch.nn.functional.mse_loss(pred, det_normal(tuple(pred.shape), case + "tgt"))
+    assert abs(loss.item() - float(g[f"{case}/loss"])) < 1e-5
+    loss.backward()
+    n = 0
+    for k, v in sd.items():
+        if f"{case}/grad/{k}" in g.files and v.grad is not None:
+            ref = g[f"{case}/grad/{k}"]
+            assert abs(grad_digest_of(v.grad)[0] - ref[0]) <= 1e-4 * ref[0] + 1e-6, k
+            n += 1
+    assert n > 20
+
+
 @pytest.mark.parametrize("case", ["v1_relu", "v1_gelu_rgb", "v1_plain"])
 def test_g16_legacy_unet(case):
     """UNet v1 (rho_diffusion/models/unet.py:30-269): forward, loss and every parameter's gradient norm from the reference class."""
