@@ -1626,7 +1626,7 @@ class _Plan:
             O = lin.weight.shape[0]
             dptr = self.dfilm.data_ptr() + 4 * off
             emit(lambda s, lin=lin, dptr=dptr, O=O, first=first: L.rho_linear_bwd(
-                dptr, film_stride, ptr(self.emb), ptr(lin.weight), pgrad(lin.weight), pgrad(lin.bias), ptr(self.demb), B, e, O, 1, 1,
+                dptr, film_stride, ptr(self.emb), ptr(lin.weight), pgrad(lin.weight), pgrad(lin.bias), ptr(self.demb), B, e, O, eng.act, 1,
                 0 if first else 1, s), "linear_bwd", flops=4.0 * B * e * O)
             first = False
             emb_params += [lin.weight, lin.bias]
