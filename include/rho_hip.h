@@ -455,6 +455,24 @@ int rho_gn_bwd_apply(const void* g, const void* x1, int64_t c1, const void* x2, 
                      int64_t s, const float* a, const float* b, int pre_silu, const float* cA, const float* cP,
                      const float* cQ, void* dx1, void* dx2, int acc1, int acc2, const void* add1, void* stream);
 
+/* Dropout forms (ABI 7): nn.Dropout(p) of ResBlock.out_layers (unet_v2.py:239: normalization, activation, Dropout, conv) as a
+ * counter-based mask over the activated tensor [N, S, C] - element e keeps its value, scaled by 1 / (1 - p), iff word (e & 3) of
+ * Philox4x32-10(counter = *drop_offset_dev + (e >> 2), key = drop_seed) >= p * 2^32.  rho_gn_apply_drop writes dropout(act(a x + b));
+ * the two backward passes multiply the incoming gradient by the same regenerated mask (nothing is stored).  drop_p in (0, 1);
+ * drop_offset_dev: uint64[1] on the device (the caller advances it once per training forward, rho_step_advance).  rho_dropout_mask
+ * writes the mask alone as bytes (test aid: lets the CPU oracle apply the very mask the kernels used). */
+int rho_gn_apply_drop(const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t n, int64_t s, const float* a,
+                      const float* b, int pre_silu, void* y, float drop_p, uint64_t drop_seed, const uint64_t* drop_offset_dev,
+                      void* stream);
+int rho_gn_bwd_reduce_drop(const void* g, const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t n, int64_t s,
+                           const float* a, const float* b, const float* stats, int pre_silu, float* partials, float drop_p,
+                           uint64_t drop_seed, const uint64_t* drop_offset_dev, void* stream);
+int rho_gn_bwd_apply_drop(const void* g, const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t n, int64_t s,
+                          const float* a, const float* b, int pre_silu, const float* cA, const float* cP, const float* cQ, void* dx1,
+                          void* dx2, int acc1, int acc2, const void* add1, float drop_p, uint64_t drop_seed,
+                          const uint64_t* drop_offset_dev, void* stream);
+int rho_dropout_mask(uint8_t* out, int64_t n, float drop_p, uint64_t drop_seed, const uint64_t* drop_offset_dev, void* stream);
+
 /* rho_gn_finalize over one or two sources (the virtual concat), each with its own partial-sum format:
  *   fmt 0: rho_gn_partial's layout  [n][nblk][c/8][16]  (8 sums, 8 sums of squares per channel octet)
  *   fmt 1: a convolution's fused epilogue statistics  [n][nblk][2][c]  (rho_conv_desc.stats, nblk = tiles)

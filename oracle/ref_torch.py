@@ -131,10 +131,12 @@ def _act(cfg_or_name) -> "callable":
 
 
 def resblock(dims: int, x: Tensor, emb: Tensor, sd: Dict[str, Tensor], p: str,
-             use_scale_shift_norm: bool, updown: Optional[str] = None, act=F.silu) -> Tensor:
+             use_scale_shift_norm: bool, updown: Optional[str] = None, act=F.silu, drop=None) -> Tensor:
     """rho_diffusion/models/unet_v2.py:273-293 (ResBlock._forward, dropout 0).  updown = "up" / "down": the activated input and
     the skip input are resampled before the first conv (:277-281; Upsample / Downsample without conv, :221-224).  ``act``: the
-    activation the block was built with (:201,214,230,238)."""
+    activation the block was built with (:201,214,230,238).  ``drop`` = (mask [N, C, *spatial] of 0 / 1, p): nn.Dropout(p) of
+    out_layers in training mode (:239) with the mask INJECTED - h <- act(h) * mask / (1 - p) - as the tests inject noise tapes."""
+    dm = (lambda v: v) if drop is None else (lambda v: v * drop[0].to(v.dtype) / (1.0 - drop[1]))
     h = act(group_norm32(x, sd[p + "in_layers.0.weight"], sd[p + "in_layers.0.bias"]))
     if updown is not None:
         rs = (lambda v: upsample(dims, v)) if updown == "up" else (lambda v: avg_pool(dims, v))
@@ -146,11 +148,11 @@ def resblock(dims: int, x: Tensor, emb: Tensor, sd: Dict[str, Tensor], p: str,
     if use_scale_shift_norm:
         scale, shift = torch.chunk(emb_out, 2, dim=1)
         h = group_norm32(h, sd[p + "out_layers.0.weight"], sd[p + "out_layers.0.bias"]) * (1 + scale) + shift
-        h = conv_nd(dims, act(h), sd[p + "out_layers.3.weight"], sd[p + "out_layers.3.bias"], padding=1)
+        h = conv_nd(dims, dm(act(h)), sd[p + "out_layers.3.weight"], sd[p + "out_layers.3.bias"], padding=1)
     else:
         h = h + emb_out
         h = group_norm32(h, sd[p + "out_layers.0.weight"], sd[p + "out_layers.0.bias"])
-        h = conv_nd(dims, act(h), sd[p + "out_layers.3.weight"], sd[p + "out_layers.3.bias"], padding=1)
+        h = conv_nd(dims, dm(act(h)), sd[p + "out_layers.3.weight"], sd[p + "out_layers.3.bias"], padding=1)
     if (p + "skip_connection.weight") in sd:
         w = sd[p + "skip_connection.weight"]
         pad = 1 if w.shape[-1] == 3 else 0
@@ -259,9 +261,9 @@ def _run_layers(dims, layers, h, emb, sd, cfg):
         if kind == "conv":
             h = conv_nd(dims, h, sd[p + "weight"], sd[p + "bias"], padding=1)
         elif kind == "res":
-            h = resblock(dims, h, emb, sd, p, ssn, act=act)
+            h = resblock(dims, h, emb, sd, p, ssn, act=act, drop=(cfg.get("_drop_masks") or {}).get(p))
         elif kind in ("res_up", "res_down"):
-            h = resblock(dims, h, emb, sd, p, ssn, updown=kind[4:], act=act)
+            h = resblock(dims, h, emb, sd, p, ssn, updown=kind[4:], act=act, drop=(cfg.get("_drop_masks") or {}).get(p))
         elif kind == "pool":
             h = avg_pool(dims, h)
         elif kind == "up_only":

@@ -68,6 +68,50 @@ __device__ __forceinline__ float dact_other_f(float u, int act) {
     }
 }
 
+// ---- counter-based RNG shared by rho_philox_normal and the dropout masks of the GroupNorm passes
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__device__ __forceinline__ void philox4x32_10(uint64_t ctr, uint64_t seed, uint32_t (&out)[4]) {
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+// Dropout (nn.Dropout(p) of ResBlock.out_layers, unet_v2.py:239) as a Philox mask over the activated tensor [N, S, C]: element e keeps
+// its value (scaled by 1 / (1 - p)) iff word (e & 3) of Philox(counter = *off_dev + (e >> 2), seed) >= p * 2^32.  The same (seed,
+// counter) regenerates the mask in the backward passes: nothing is stored.
+struct DropK {
+    uint32_t thr;            // p * 2^32 (p < 1)
+    float inv_keep;          // 1 / (1 - p)
+    uint64_t seed;
+    const uint64_t* off_dev; // uint64[1] on the device: advanced by the engine once per training forward
+};
+// multipliers of the 8 consecutive elements e0 .. e0 + 7 (e0 a multiple of 8)
+__device__ __forceinline__ void drop_mult8(const DropK& dk, uint64_t off, int64_t e0, float (&m)[8]) {
+    uint32_t r0[4], r1[4];
+    philox4x32_10(off + ((uint64_t)e0 >> 2), dk.seed, r0);
+    philox4x32_10(off + ((uint64_t)e0 >> 2) + 1, dk.seed, r1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        m[j] = r0[j] >= dk.thr ? dk.inv_keep : 0.0f;
+        m[4 + j] = r1[j] >= dk.thr ? dk.inv_keep : 0.0f;
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

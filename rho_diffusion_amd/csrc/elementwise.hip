@@ -160,28 +160,6 @@ extern "C" int rho_step_advance(int32_t* t_dev, uint64_t* offset_dev, uint64_t d
 }
 
 // ----------------------------------------------------------------------------- Philox4x32-10 normals
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
-
-__device__ __forceinline__ void philox4x32_10(uint64_t ctr, uint64_t seed, uint32_t (&out)[4]) {
-    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        philox_round(c, k0, k1);
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
-}
-
 __device__ __forceinline__ void box_muller(uint32_t u0, uint32_t u1, float& a, float& b) {
     const float f0 = ((float)(u0 >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
     const float f1 = ((float)(u1 >> 8) + 0.5f) * (1.0f / 16777216.0f);

@@ -309,12 +309,13 @@ extern "C" int rho_gn_finalize2(const float* p1, int fmt1, int64_t nblk1, int64_
 // forward statistics) give every parameter / FiLM gradient and the group means, so pass 2 is a pure
 // elementwise   dx = A[n,c]*gq + P[n,grp] + Q[n,grp]*x .
 
-template <typename T>
+// DROP: the forward applied a dropout mask after the activation (rho_gn_apply_drop): g is multiplied by the regenerated mask
+template <typename T, bool DROP = false>
 __global__ __launch_bounds__(256) void k_gn_bwd_reduce(const T* __restrict__ g, const T* __restrict__ x1, int c1,
                                                        const T* __restrict__ x2, int c2, int64_t s, int nblk,
                                                        const float* __restrict__ a, const float* __restrict__ b,
                                                        const float* __restrict__ stats, int pre_silu,
-                                                       float* __restrict__ partials) {
+                                                       float* __restrict__ partials, DropK dk = DropK{}) {
     __shared__ float red[256 * 17];
     const int C = c1 + c2;
     const int OCT = C >> 3;
@@ -350,6 +351,8 @@ __global__ __launch_bounds__(256) void k_gn_bwd_reduce(const T* __restrict__ g, 
             mu[j] = stats[((int64_t)n * 32 + grp) * 2 + 0];
             rs[j] = stats[((int64_t)n * 32 + grp) * 2 + 1];
         }
+        uint64_t doff = 0;
+        if constexpr (DROP) doff = *dk.off_dev;
         int64_t p = p0 + pl;
         for (; p + ppi < p1; p += 2 * (int64_t)ppi) {      // two positions (4 loads) in flight
             float xv[8], gv[8], xw[8], gw[8];
@@ -357,6 +360,13 @@ __global__ __launch_bounds__(256) void k_gn_bwd_reduce(const T* __restrict__ g, 
             load_octet<T>(gp + p * C, gv);
             load_octet<T>(src + (p + ppi) * stride, xw);
             load_octet<T>(gp + (p + ppi) * C, gw);
+            if constexpr (DROP) {
+                float mv[8], mw[8];
+                drop_mult8(dk, doff, ((int64_t)n * s + p) * C + ch, mv);
+                drop_mult8(dk, doff, ((int64_t)n * s + p + ppi) * C + ch, mw);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { gv[j] *= mv[j]; gw[j] *= mw[j]; }
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float gq = gv[j], gr = gw[j];
@@ -375,6 +385,12 @@ __global__ __launch_bounds__(256) void k_gn_bwd_reduce(const T* __restrict__ g, 
             float xv[8], gv[8];
             load_octet<T>(src + p * stride, xv);
             load_octet<T>(gp + p * C, gv);
+            if constexpr (DROP) {
+                float mv[8];
+                drop_mult8(dk, doff, ((int64_t)n * s + p) * C + ch, mv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gv[j] *= mv[j];
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float gq = gv[j];
@@ -398,6 +414,39 @@ __global__ __launch_bounds__(256) void k_gn_bwd_reduce(const T* __restrict__ g, 
     }
 }
 
+static inline bool drop_args(float p, uint64_t seed, const uint64_t* off_dev, DropK& dk) {
+    if (!(p > 0.0f) || !(p < 1.0f) || !off_dev) return false;
+    dk.thr = (uint32_t)((double)p * 4294967296.0);
+    dk.inv_keep = 1.0f / (1.0f - p);
+    dk.seed = seed;
+    dk.off_dev = off_dev;
+    return true;
+}
+
+// (the dropout form: drop_p in (0, 1), the mask of rho_gn_apply_drop with the same seed / offset; see rho_hip.h)
+extern "C" int rho_gn_bwd_reduce_drop(const void* g, const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t n,
+                                      int64_t s, const float* a, const float* b, const float* stats, int pre_silu, float* partials,
+                                      float drop_p, uint64_t drop_seed, const uint64_t* drop_offset_dev, void* stream) {
+    if (!g || !x1 || !a || !b || !stats || !partials || n <= 0 || s <= 0) return RHO_E_ARG;
+    DropK dk{};
+    if (!drop_args(drop_p, drop_seed, drop_offset_dev, dk)) return RHO_E_ARG;
+    if (!x2) c2 = 0;
+    const int64_t C = c1 + c2;
+    if (C % 32 != 0 || c1 % 8 != 0 || c2 % 8 != 0 || C > 2048) return RHO_E_ALIGN;
+    const int nblk = rho_gn_nblk(s);
+    dim3 grid(nblk, (unsigned)n), block(256);
+    if (dtype == RHO_BF16)
+        hipLaunchKernelGGL((k_gn_bwd_reduce<bf16_raw, true>), grid, block, 0, as_stream(stream), (const bf16_raw*)g, (const bf16_raw*)x1,
+                           (int)c1, (const bf16_raw*)x2, (int)c2, s, nblk, a, b, stats, pre_silu, partials, dk);
+    else if (dtype == RHO_F32)
+        hipLaunchKernelGGL((k_gn_bwd_reduce<float, true>), grid, block, 0, as_stream(stream), (const float*)g, (const float*)x1, (int)c1,
+                           (const float*)x2, (int)c2, s, nblk, a, b, stats, pre_silu, partials, dk);
+    else
+        return RHO_E_ARG;
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int rho_gn_bwd_reduce(const void* g, const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t n,
                                  int64_t s, const float* a, const float* b, const float* stats, int pre_silu, float* partials,
                                  void* stream) {
@@ -408,11 +457,11 @@ extern "C" int rho_gn_bwd_reduce(const void* g, const void* x1, int64_t c1, cons
     const int nblk = rho_gn_nblk(s);
     dim3 grid(nblk, (unsigned)n), block(256);
     if (dtype == RHO_BF16)
-        hipLaunchKernelGGL(k_gn_bwd_reduce<bf16_raw>, grid, block, 0, as_stream(stream), (const bf16_raw*)g, (const bf16_raw*)x1,
-                           (int)c1, (const bf16_raw*)x2, (int)c2, s, nblk, a, b, stats, pre_silu, partials);
+        hipLaunchKernelGGL((k_gn_bwd_reduce<bf16_raw, false>), grid, block, 0, as_stream(stream), (const bf16_raw*)g, (const bf16_raw*)x1,
+                           (int)c1, (const bf16_raw*)x2, (int)c2, s, nblk, a, b, stats, pre_silu, partials, DropK{});
     else if (dtype == RHO_F32)
-        hipLaunchKernelGGL(k_gn_bwd_reduce<float>, grid, block, 0, as_stream(stream), (const float*)g, (const float*)x1, (int)c1,
-                           (const float*)x2, (int)c2, s, nblk, a, b, stats, pre_silu, partials);
+        hipLaunchKernelGGL((k_gn_bwd_reduce<float, false>), grid, block, 0, as_stream(stream), (const float*)g, (const float*)x1, (int)c1,
+                           (const float*)x2, (int)c2, s, nblk, a, b, stats, pre_silu, partials, DropK{});
     else
         return RHO_E_ARG;
     RHO_LAUNCH_CHECK();
@@ -577,13 +626,13 @@ __device__ __forceinline__ float cvt_round<float>(float v) { return v; }
 template <>
 __device__ __forceinline__ float cvt_round<bf16_raw>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
 
-template <typename T>
+template <typename T, bool DROP = false>
 __global__ __launch_bounds__(256) void k_gn_bwd_apply(const T* __restrict__ g, const T* __restrict__ x1, int c1,
                                                       const T* __restrict__ x2, int c2, int64_t s, int nblk,
                                                       const float* __restrict__ a, const float* __restrict__ b, int pre_silu,
                                                       const float* __restrict__ cA, const float* __restrict__ cP,
                                                       const float* __restrict__ cQ, T* __restrict__ dx1, T* __restrict__ dx2,
-                                                      int acc1, int acc2, const T* __restrict__ add1) {
+                                                      int acc1, int acc2, const T* __restrict__ add1, DropK dk = DropK{}) {
     // same thread -> (channel octet, position lane) map as the reducers: the 5 per-channel coefficients live in
     // registers for the whole position walk (the elementwise form re-loaded them and divided indices per element)
     const int C = c1 + c2;
@@ -614,10 +663,18 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(const T* __restrict__ g, c
         av[j] = a[nc]; bv[j] = b[nc]; ca[j] = cA[nc];
         cp[j] = cP[(int64_t)n * 32 + grp]; cq[j] = cQ[(int64_t)n * 32 + grp];
     }
+    uint64_t doff = 0;
+    if constexpr (DROP) doff = *dk.off_dev;
     for (int64_t p = p0 + pl; p < p1; p += ppi) {
         float xv[8], gv[8], ov[8];
         load_octet<T>(xs + p * stride, xv);
         load_octet<T>(gp + p * C, gv);
+        if constexpr (DROP) {
+            float mv[8];
+            drop_mult8(dk, doff, ((int64_t)n * s + p) * C + ch, mv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gv[j] *= mv[j];
+        }
         float ev[8];
         if (accf) load_octet<T>(dst + p * stride, ov);
         if (e1) load_octet<T>(e1 + p * stride, ev);
@@ -637,9 +694,28 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(const T* __restrict__ g, c
     }
 }
 
+static int gn_bwd_apply_impl(const void* g, const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t n,
+                             int64_t s, const float* a, const float* b, int pre_silu, const float* cA, const float* cP,
+                             const float* cQ, void* dx1, void* dx2, int acc1, int acc2, const void* add1, const DropK* dkp, void* stream);
+
+extern "C" int rho_gn_bwd_apply_drop(const void* g, const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t n,
+                                     int64_t s, const float* a, const float* b, int pre_silu, const float* cA, const float* cP,
+                                     const float* cQ, void* dx1, void* dx2, int acc1, int acc2, const void* add1, float drop_p,
+                                     uint64_t drop_seed, const uint64_t* drop_offset_dev, void* stream) {
+    DropK dk{};
+    if (!drop_args(drop_p, drop_seed, drop_offset_dev, dk)) return RHO_E_ARG;
+    return gn_bwd_apply_impl(g, x1, c1, x2, c2, dtype, n, s, a, b, pre_silu, cA, cP, cQ, dx1, dx2, acc1, acc2, add1, &dk, stream);
+}
+
 extern "C" int rho_gn_bwd_apply(const void* g, const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t n,
                                 int64_t s, const float* a, const float* b, int pre_silu, const float* cA, const float* cP,
                                 const float* cQ, void* dx1, void* dx2, int acc1, int acc2, const void* add1, void* stream) {
+    return gn_bwd_apply_impl(g, x1, c1, x2, c2, dtype, n, s, a, b, pre_silu, cA, cP, cQ, dx1, dx2, acc1, acc2, add1, nullptr, stream);
+}
+
+static int gn_bwd_apply_impl(const void* g, const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t n,
+                             int64_t s, const float* a, const float* b, int pre_silu, const float* cA, const float* cP,
+                             const float* cQ, void* dx1, void* dx2, int acc1, int acc2, const void* add1, const DropK* dkp, void* stream) {
     if (!g || !x1 || !a || !b || !cA || !cP || !cQ || !dx1 || n <= 0 || s <= 0) return RHO_E_ARG;
     if (!x2) c2 = 0;
     if (c2 > 0 && !dx2) return RHO_E_ARG;
@@ -648,15 +724,18 @@ extern "C" int rho_gn_bwd_apply(const void* g, const void* x1, int64_t c1, const
     if (C > 2048) return RHO_E_SHAPE;
     const int nblk = apply_nblk(s, 512, C, n);  // finer than the reducers: nothing to combine afterwards
     dim3 grid((unsigned)nblk, (unsigned)n), block(256);
-    if (dtype == RHO_BF16)
-        hipLaunchKernelGGL(k_gn_bwd_apply<bf16_raw>, grid, block, 0, as_stream(stream), (const bf16_raw*)g, (const bf16_raw*)x1,
-                           (int)c1, (const bf16_raw*)x2, (int)c2, s, nblk, a, b, pre_silu, cA, cP, cQ, (bf16_raw*)dx1, (bf16_raw*)dx2,
-                           acc1, acc2, (const bf16_raw*)add1);
-    else if (dtype == RHO_F32)
-        hipLaunchKernelGGL(k_gn_bwd_apply<float>, grid, block, 0, as_stream(stream), (const float*)g, (const float*)x1, (int)c1,
-                           (const float*)x2, (int)c2, s, nblk, a, b, pre_silu, cA, cP, cQ, (float*)dx1, (float*)dx2, acc1, acc2, (const float*)add1);
-    else
-        return RHO_E_ARG;
+    if (dtype != RHO_BF16 && dtype != RHO_F32) return RHO_E_ARG;
+#define RHO_APPLY(T_, DROP_, DK_)                                                                                                      \
+    hipLaunchKernelGGL((k_gn_bwd_apply<T_, DROP_>), grid, block, 0, as_stream(stream), (const T_*)g, (const T_*)x1, (int)c1, (const T_*)x2, \
+                       (int)c2, s, nblk, a, b, pre_silu, cA, cP, cQ, (T_*)dx1, (T_*)dx2, acc1, acc2, (const T_*)add1, DK_)
+    if (dkp) {
+        if (dtype == RHO_BF16) RHO_APPLY(bf16_raw, true, *dkp);
+        else RHO_APPLY(float, true, *dkp);
+    } else {
+        if (dtype == RHO_BF16) RHO_APPLY(bf16_raw, false, DropK{});
+        else RHO_APPLY(float, false, DropK{});
+    }
+#undef RHO_APPLY
     RHO_LAUNCH_CHECK();
     return 0;
 }
@@ -666,10 +745,10 @@ extern "C" int rho_gn_bwd_apply(const void* g, const void* x1, int64_t c1, const
 // of one or two sources.  The forward convolutions never need it (their loaders apply the folded affine on the
 // fly); the weight gradient does: there every (cout-tile, cin-chunk) workgroup would otherwise redo the
 // exp/rcp of SiLU for the same input chunk with a single wave per SIMD to hide it.
-template <typename T>
+template <typename T, bool DROP = false>
 __global__ __launch_bounds__(256) void k_gn_apply(const T* __restrict__ x1, int c1, const T* __restrict__ x2, int c2, int64_t s,
                                                   int nblk, const float* __restrict__ a, const float* __restrict__ b,
-                                                  int pre_silu, T* __restrict__ y) {
+                                                  int pre_silu, T* __restrict__ y, DropK dk = DropK{}) {
     const int C = c1 + c2;
     const int OCT = C >> 3;
     const int ppi = 256 / OCT;
@@ -691,6 +770,8 @@ __global__ __launch_bounds__(256) void k_gn_apply(const T* __restrict__ x1, int 
         av[j] = a[(int64_t)n * C + ch + j];
         bv[j] = b[(int64_t)n * C + ch + j];
     }
+    uint64_t doff = 0;
+    if constexpr (DROP) doff = *dk.off_dev;
     int64_t p = p0 + pl;
     for (; p + 3 * ppi < p1; p += 4 * ppi) {       // four independent 16/32-byte loads in flight per thread
         float xv[4][8];
@@ -703,6 +784,12 @@ __global__ __launch_bounds__(256) void k_gn_apply(const T* __restrict__ x1, int 
                 const float f = fmaf(av[j], xv[u][j], bv[j]);
                 xv[u][j] = pre_silu == 1 ? silu_f(f) : (pre_silu ? act_other_f(f, pre_silu) : f);
             }
+            if constexpr (DROP) {
+                float mv[8];
+                drop_mult8(dk, doff, ((int64_t)n * s + p + u * ppi) * C + ch, mv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xv[u][j] *= mv[j];
+            }
             store_octet<T>(yp + (p + u * ppi) * C, xv[u]);
         }
     }
@@ -714,12 +801,54 @@ __global__ __launch_bounds__(256) void k_gn_apply(const T* __restrict__ x1, int 
             const float f = fmaf(av[j], xv[j], bv[j]);
             xv[j] = pre_silu == 1 ? silu_f(f) : (pre_silu ? act_other_f(f, pre_silu) : f);
         }
+        if constexpr (DROP) {
+            float mv[8];
+            drop_mult8(dk, doff, ((int64_t)n * s + p) * C + ch, mv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[j] *= mv[j];
+        }
         store_octet<T>(yp + p * C, xv);
     }
 }
 
+static int gn_apply_impl(const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t n, int64_t s, const float* a,
+                         const float* b, int pre_silu, void* y, const DropK* dkp, void* stream);
+
+extern "C" int rho_gn_apply_drop(const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t n, int64_t s,
+                                 const float* a, const float* b, int pre_silu, void* y, float drop_p, uint64_t drop_seed,
+                                 const uint64_t* drop_offset_dev, void* stream) {
+    DropK dk{};
+    if (!drop_args(drop_p, drop_seed, drop_offset_dev, dk)) return RHO_E_ARG;
+    return gn_apply_impl(x1, c1, x2, c2, dtype, n, s, a, b, pre_silu, y, &dk, stream);
+}
+
+// the mask alone, as bytes (1 = kept): what rho_gn_apply_drop applies to element e of its output (test aid; n elements)
+__global__ __launch_bounds__(256) void k_dropout_mask(uint8_t* __restrict__ out, int64_t n, DropK dk) {
+    const uint64_t off = *dk.off_dev;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += (int64_t)gridDim.x * blockDim.x * 8) {
+        float m[8];
+        drop_mult8(dk, off, i, m);
+        for (int j = 0; j < 8 && i + j < n; ++j) out[i + j] = m[j] != 0.0f ? 1 : 0;
+    }
+}
+extern "C" int rho_dropout_mask(uint8_t* out, int64_t n, float drop_p, uint64_t drop_seed, const uint64_t* drop_offset_dev, void* stream) {
+    DropK dk{};
+    if (!out || n <= 0 || !drop_args(drop_p, drop_seed, drop_offset_dev, dk)) return RHO_E_ARG;
+    int64_t g = (n / 8 + 255) / 256;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_dropout_mask, dim3((unsigned)g), dim3(256), 0, as_stream(stream), out, n, dk);
+    RHO_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int rho_gn_apply(const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t n, int64_t s,
                             const float* a, const float* b, int pre_silu, void* y, void* stream) {
+    return gn_apply_impl(x1, c1, x2, c2, dtype, n, s, a, b, pre_silu, y, nullptr, stream);
+}
+
+static int gn_apply_impl(const void* x1, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t n, int64_t s, const float* a,
+                         const float* b, int pre_silu, void* y, const DropK* dkp, void* stream) {
     if (!x1 || !a || !b || !y || n <= 0 || s <= 0) return RHO_E_ARG;
     if (!x2) c2 = 0;
     const int64_t C = c1 + c2;
@@ -727,14 +856,18 @@ extern "C" int rho_gn_apply(const void* x1, int64_t c1, const void* x2, int64_t 
     if (C > 2048 || n > 65535) return RHO_E_SHAPE;
     const int nblk = apply_nblk(s, 1024, C, n);
     dim3 grid((unsigned)nblk, (unsigned)n), block(256);
-    if (dtype == RHO_BF16)
-        hipLaunchKernelGGL(k_gn_apply<bf16_raw>, grid, block, 0, as_stream(stream), (const bf16_raw*)x1, (int)c1, (const bf16_raw*)x2,
-                           (int)c2, s, nblk, a, b, pre_silu, (bf16_raw*)y);
-    else if (dtype == RHO_F32)
-        hipLaunchKernelGGL(k_gn_apply<float>, grid, block, 0, as_stream(stream), (const float*)x1, (int)c1, (const float*)x2, (int)c2, s,
-                           nblk, a, b, pre_silu, (float*)y);
-    else
-        return RHO_E_ARG;
+    if (dtype != RHO_BF16 && dtype != RHO_F32) return RHO_E_ARG;
+#define RHO_GNA(T_, DROP_, DK_)                                                                                                        \
+    hipLaunchKernelGGL((k_gn_apply<T_, DROP_>), grid, block, 0, as_stream(stream), (const T_*)x1, (int)c1, (const T_*)x2, (int)c2, s, nblk, \
+                       a, b, pre_silu, (T_*)y, DK_)
+    if (dkp) {
+        if (dtype == RHO_BF16) RHO_GNA(bf16_raw, true, *dkp);
+        else RHO_GNA(float, true, *dkp);
+    } else {
+        if (dtype == RHO_BF16) RHO_GNA(bf16_raw, false, DropK{});
+        else RHO_GNA(float, false, DropK{});
+    }
+#undef RHO_GNA
     RHO_LAUNCH_CHECK();
     return 0;
 }

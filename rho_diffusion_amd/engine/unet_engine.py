@@ -531,7 +531,9 @@ class UNetEngine:
         A change of any of them selects (builds) another plan instead of silently replaying the old one."""
         ck = tuple(bool(b.use_checkpoint) for b in self._film_blocks)
         env = tuple(os.environ.get(k) for k in self._PLAN_ENV)
-        return (ck, ops.deterministic(), env)
+        # nn.Dropout is active iff the module is in training mode (with or without autograd): part of the key where p > 0
+        drop = bool(self.model.training) if any(float(getattr(b, "dropout", 0.0) or 0.0) > 0.0 for b in self._film_blocks) else None
+        return (ck, ops.deterministic(), env, drop)
 
     def drop_plans(self, train_only: bool = False) -> None:
         """Release cached plans (and their device buffers): all of them, or only the training plans."""
@@ -584,6 +586,12 @@ class _Plan:
         self.fwd_descs: List[object] = []          # rho_conv_desc of every forward / data-gradient launch (variants())
         self.wgrad_descs: List[tuple] = []         # (forward-shaped descriptor, dY row width) of every weight-gradient launch
         self.cond_src = None
+        # dropout (nn.Dropout(p) of ResBlock.out_layers, unet_v2.py:239; active iff the model is in training mode): Philox masks in the
+        # materialising pass, regenerated in backward from (seed of the block, a device counter advanced once per forward)
+        self.drop_active = bool(eng.model.training) and any(float(getattr(b, "dropout", 0.0) or 0.0) > 0.0 for b in eng._film_blocks)
+        self.drop_ctr = torch.zeros(1, dtype=torch.int64, device=eng.device) if self.drop_active else None
+        self.drop_delta = 0
+        self.drop_nodes: List[dict] = []          # (test aid) block, p, seed, activated-tensor shape of every dropout site
         L = hip.lib()
         self.L = L
         B = xshape[0]
@@ -677,7 +685,7 @@ class _Plan:
             return dict(x1=x1, x2=x2, norm=norm, film_off=off, a=a, b=b, st=st, part=part, N=N, S=S, C=Cc, nblk=nblk)
 
         def conv(x1, x2, cw, *, stride_hw=(1, 1), up_hw=(0, 0), pre=None, pre_silu=False, res=None, res_add_off=None,
-                 split=None, y2_dtype=None, stem=False, want_stats=True, ckpt=False, fold_skip=None, node_res=None):
+                 split=None, y2_dtype=None, stem=False, want_stats=True, ckpt=False, fold_skip=None, node_res=None, drop=None):
             cout = cw.cout
             split_ = cout if split is None else split
             N, Do, Ho, Wo = ops.conv_out_shape(x1.shape, cw.kernel, stride_hw, up_hw)
@@ -701,7 +709,9 @@ class _Plan:
             other_act = pre is not None and int(pre_silu) > 1
             if other_act and up_hw != (0, 0):
                 raise hip.RhoHipError("internal: a normalised conv behind an upsample with a non-SiLU activation")
-            if pre is not None and up_hw == (0, 0) and (keep_act or wide_1x1 or wide_3x3 or other_act):
+            if drop is not None and (pre is None or up_hw != (0, 0)):
+                raise hip.RhoHipError("internal: dropout on a conv without a materialisable normalised input")
+            if pre is not None and up_hw == (0, 0) and (keep_act or wide_1x1 or wide_3x3 or other_act or drop is not None):
                 # training: the activated input act(a*x+b) is needed twice (this conv, its weight gradient) and the conv
                 # loader would recompute it 2.3x (halo) per cout tile: materialise it once (one HBM-rate pass, kept for
                 # backward: +1 activation-sized buffer per normalised conv, 38 GB at c3) and feed both from it
@@ -710,7 +720,13 @@ class _Plan:
                 xact = (buf if keep_act else scratch)(*x1.shape[:4], c1_ + c2_)
                 Sx = x1.shape[1] * x1.shape[2] * x1.shape[3]
                 ga = (ptr(x1), c1_, ptr(x2), c2_, dtc, x1.shape[0], Sx, ptr(pre["a"]), ptr(pre["b"]), int(pre_silu), ptr(xact))
-                self.ops.append(lambda s, a=ga: L.rho_gn_apply(*a, s))
+                if drop is not None:
+                    gd = ga + (float(drop[0]), int(drop[1]), ptr(self.drop_ctr))
+                    self.ops.append(lambda s, a=gd: L.rho_gn_apply_drop(*a, s))
+                    self.drop_delta = max(self.drop_delta, (xact.numel() + 3) // 4)
+                    self.drop_nodes.append(dict(blk=drop[2], p=float(drop[0]), seed=int(drop[1]), shape=tuple(xact.shape)))
+                else:
+                    self.ops.append(lambda s, a=ga: L.rho_gn_apply(*a, s))
                 self.info.append(dict(kind="gn_apply", flops=0.0, bytes=2.0 * esz * xact.numel()))
                 cx1, cx2, cpre = xact, None, None
             # A conv behind a nearest x2 upsample as one 2-tap launch per output parity on the SOURCE tensor (rho_conv_desc.ph_h):
@@ -773,7 +789,7 @@ class _Plan:
             self.nodes.append(dict(k="conv", cw=cw, x1=x1, x2=x2, y=y, y2=y2, stride_hw=stride_hw, up_hw=up_hw, pre=pre,
                                    pre_silu=pre_silu, res=res if node_res is None else node_res, res_add_off=res_add_off, stem=stem,
                                    out_dims=(N, Do, Ho, Wo),
-                                   xact=xact if keep_act else None, phased=phased, s2=s2))
+                                   xact=xact if keep_act else None, phased=phased, s2=s2, drop=drop))
             return y, y2
 
         rs_hw = (1, 1) if dims >= 2 else (0, 1)      # axes a Down/Upsample touches: H and W (3-D: depth stays), 1-D: W only
@@ -807,6 +823,15 @@ class _Plan:
             self.nodes.append(dict(k="act", x1=x1, x2=x2, pre=pre, pre_silu=pre_silu, y=yt))
             return yt
 
+        def drop_of(blk):
+            """(p, seed, block) of the block's nn.Dropout when it is active in this plan, else None: one Philox key per block."""
+            p_ = float(getattr(blk, "dropout", 0.0) or 0.0)
+            if not self.drop_active or p_ <= 0.0:
+                return None
+            idx = eng._film_blocks.index(blk)
+            seed = (int(getattr(eng.model, "dropout_seed", 777)) + 0x9E3779B97F4A7C15 * (idx + 1)) & 0xFFFFFFFFFFFFFFFF
+            return (p_, seed, blk)
+
         def resblock_updown(blk, h1, h2):
             from ..models.unet_v2 import Upsample as _Up
             mode = "up" if isinstance(blk.h_upd, _Up) else "avg"
@@ -822,7 +847,7 @@ class _Plan:
                 sk = x1p
             else:
                 sk, _ = conv(x1p, x2p, eng._conv(blk.skip_connection))
-            out, _ = conv(t1, None, eng._conv(blk.out_layers[3]), pre=g2, pre_silu=eng.act, res=sk, ckpt=bool(blk.use_checkpoint))
+            out, _ = conv(t1, None, eng._conv(blk.out_layers[3]), pre=g2, pre_silu=eng.act, res=sk, ckpt=bool(blk.use_checkpoint), drop=drop_of(blk))
             return out
 
         def resblock(blk, h1, h2):
@@ -856,7 +881,7 @@ class _Plan:
                             self.nodes.append(dict(k="conv", cw=skw, x1=h1, x2=h2, y=skd, y2=None, stride_hw=(1, 1), up_hw=(0, 0), pre=None,
                                                    pre_silu=False, res=None, res_add_off=None, stem=False, out_dims=(N_, D_, H_, W_),
                                                    xact=None, phased=False, s2=False))
-                        out, _ = conv(t1, None, ocw, pre=g2, pre_silu=eng.act, ckpt=ck, fold_skip=fs, node_res=skd)
+                        out, _ = conv(t1, None, ocw, pre=g2, pre_silu=eng.act, ckpt=ck, fold_skip=fs, node_res=skd, drop=drop_of(blk))
                         # the launch's work = the 27-tap conv + the folded 1x1x1 (both algorithmic FLOPs of the reference's
                         # formulation); the 1x1x1 share is also reported on its own (bench: roofline.folded_conv1_flops_per_step)
                         fl = 2.0 * (t1.numel() // t1.shape[-1]) * ocw.cout * skw.cin
@@ -866,7 +891,7 @@ class _Plan:
                         self.info[-1]["bytes"] += float(esz) * (t1.numel() // t1.shape[-1]) * skw.cin
                         return out
                 sk, _ = conv(h1, h2, skw)
-            out, _ = conv(t1, None, eng._conv(blk.out_layers[3]), pre=g2, pre_silu=eng.act, res=sk, ckpt=ck)
+            out, _ = conv(t1, None, eng._conv(blk.out_layers[3]), pre=g2, pre_silu=eng.act, res=sk, ckpt=ck, drop=drop_of(blk))
             return out
 
         def attention(blk, xin):
@@ -1274,7 +1299,11 @@ class _Plan:
                 Nn = x1.shape[0]
                 Sx = x1.shape[1] * x1.shape[2] * x1.shape[3]
                 a = (ptr(x1), c1_, ptr(x2), c2_, dtc, Nn, Sx, ptr(pre["a"]), ptr(pre["b"]), int(node["pre_silu"]), ptr(xact))
-                emit(lambda s, a=a: L.rho_gn_apply(*a, s), "gn_apply", nbytes=2.0 * esz * xact.numel())
+                if node.get("drop") is not None:     # the same mask as the forward: same key, same counter
+                    ad = a + (float(node["drop"][0]), int(node["drop"][1]), ptr(self.drop_ctr))
+                    emit(lambda s, a=ad: L.rho_gn_apply_drop(*a, s), "gn_apply", nbytes=2.0 * esz * xact.numel())
+                else:
+                    emit(lambda s, a=a: L.rho_gn_apply(*a, s), "gn_apply", nbytes=2.0 * esz * xact.numel())
                 x1, x2 = xact, None
             d = ops.make_conv_desc(x1, x2, cw.w, cw.b, kernel=cw.kernel, cout=cw.cout, split=cw.cout, y=dY, y2=None,
                                    stride_hw=node["stride_hw"], pre_silu=False)
@@ -1311,7 +1340,7 @@ class _Plan:
             if xact is not None:
                 wput(xact)
 
-        def gn_backward(pre, pre_silu, x1, x2, dact, fused=None):
+        def gn_backward(pre, pre_silu, x1, x2, dact, fused=None, drop=None):
             """dact = gradient of act(GroupNorm(x) * (1 + scale) + shift): reduce / finalize / apply into the gradients of x1 (, x2),
             the norm's parameters and the FiLM rows.  ``fused`` = (tile sums, tiles per sample) when the dgrad launch that produced
             dact already reduced dz and dz * x in its epilogue (rho_conv_desc.gnb_*): the reduce pass is skipped."""
@@ -1336,7 +1365,11 @@ class _Plan:
             if fused is None:
                 a1 = (ptr(dact), ptr(x1), c1, ptr(x2), c2, dtc, N_, S_, ptr(pre["a"]), ptr(pre["b"]), ptr(pre["st"]),
                       int(pre_silu), ptr(pre["part"]))
-                emit(lambda s, a=a1: L.rho_gn_bwd_reduce(*a, s), "gn_bwd_reduce", nbytes=2.0 * esz * N_ * S_ * Cc)
+                if drop is not None:
+                    a1d = a1 + (float(drop[0]), int(drop[1]), ptr(self.drop_ctr))
+                    emit(lambda s, a=a1d: L.rho_gn_bwd_reduce_drop(*a, s), "gn_bwd_reduce", nbytes=2.0 * esz * N_ * S_ * Cc)
+                else:
+                    emit(lambda s, a=a1: L.rho_gn_bwd_reduce(*a, s), "gn_bwd_reduce", nbytes=2.0 * esz * N_ * S_ * Cc)
                 part_ptr, part_n, fmt = ptr(pre["part"]), pre["nblk"], 0
             else:
                 part_ptr, part_n, fmt = ptr(fused[0]), fused[1], 1
@@ -1347,8 +1380,12 @@ class _Plan:
                      ptr(cQ), s), "gn_bwd_finalize")
             a3 = (ptr(dact), ptr(x1), c1, ptr(x2), c2, dtc, N_, S_, ptr(pre["a"]), ptr(pre["b"]), int(pre_silu),
                   ptr(cA), ptr(cP), ptr(cQ), ptr(g1), ptr(g2), int(acc1), int(acc2), ptr(add1))
-            emit(lambda s, a=a3: L.rho_gn_bwd_apply(*a, s), "gn_bwd_apply",
-                 nbytes=esz * N_ * S_ * (3.0 * Cc + (c1 if acc1 else 0) + (c2 if acc2 else 0) + (c1 if add1 is not None else 0)))
+            nb3 = esz * N_ * S_ * (3.0 * Cc + (c1 if acc1 else 0) + (c2 if acc2 else 0) + (c1 if add1 is not None else 0))
+            if drop is not None:
+                a3d = a3 + (float(drop[0]), int(drop[1]), ptr(self.drop_ctr))
+                emit(lambda s, a=a3d: L.rho_gn_bwd_apply_drop(*a, s), "gn_bwd_apply", nbytes=nb3)
+            else:
+                emit(lambda s, a=a3: L.rho_gn_bwd_apply(*a, s), "gn_bwd_apply", nbytes=nb3)
             if add1 is not None and add1.data_ptr() not in {g_.data_ptr() for g_ in G.values()}:
                 pool.put(add1)                                 # (stream order: recycled buffers are written by later launches only)
             written.add(key(x1))
@@ -1386,7 +1423,8 @@ class _Plan:
                 dact = pool.get(tshape, dt)       # gradient of the activated / upsampled tensor
                 d = ops.make_conv_desc(dY, None, cw.wd, cw.zero_bias, split=cin, y=dact, y2=None, **common)
                 fused = None
-                if pre is not None and self.fuse_gn_bwd > 0 and cin >= self.fuse_gn_bwd and int(node["pre_silu"]) <= 1:
+                if (pre is not None and self.fuse_gn_bwd > 0 and cin >= self.fuse_gn_bwd and int(node["pre_silu"]) <= 1
+                        and node.get("drop") is None):
                     # the norm's backward reductions ride in this launch's epilogue where a tile lies in one sample
                     tiles = int(L.rho_conv_stats_tiles(C.byref(d)))
                     if tiles > 0:
@@ -1402,7 +1440,7 @@ class _Plan:
                 if after_launch is not None:
                     after_launch()                    # (the deferred weight gradient starts here, on the side stream)
                 if pre is not None:
-                    gn_backward(pre, node["pre_silu"], x1, x2, dact, fused)
+                    gn_backward(pre, node["pre_silu"], x1, x2, dact, fused, drop=node.get("drop"))
                     if fused is not None:
                         pool.put(fused[0])
                 else:   # upsample: sum the 2x2 (1x2) children
@@ -1702,6 +1740,9 @@ class _Plan:
                                         ptr(self.cond), ptr(self.sin_in), ptr(self.emb_h), ptr(self.emb), self.B, eng.mc,
                                         self.emb.shape[1], eng.act, hip.stream()), "rho_timestep_embed")
         s = hip.stream()
+        if self.drop_active:
+            # a fresh stretch of every block's Philox stream for this forward (and its backward, which reads the same counter)
+            check(self.L.rho_step_advance(None, ptr(self.drop_ctr), self.drop_delta, s), "rho_step_advance")
         for op in self.ops:
             rc = op(s)
             if rc != 0:

@@ -130,6 +130,14 @@ SIGNATURES = {
                                     c_void_p]),
     "rho_gn_bwd_apply": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "rho_gn_apply_drop": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_float,
+                                  c_uint64, c_void_p, c_void_p]),
+    "rho_gn_bwd_reduce_drop": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                       c_int, c_void_p, c_float, c_uint64, c_void_p, c_void_p]),
+    "rho_gn_bwd_apply_drop": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_uint64, c_void_p,
+                                      c_void_p]),
+    "rho_dropout_mask": (c_int, [c_void_p, c_int64, c_float, c_uint64, c_void_p, c_void_p]),
     "rho_gn_apply": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "rho_ddpm_sched_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_float,
                                     c_float, c_float, c_void_p]),

@@ -8,6 +8,8 @@ activations that never round-trip through PyTorch ops.
 """
 from __future__ import annotations
 
+import os
+
 from abc import abstractmethod
 from typing import Optional
 
@@ -105,10 +107,8 @@ class ResBlock(TimestepBlock):
                  use_scale_shift_norm=False, dims=2, use_checkpoint=False, up=False, down=False,
                  activation=nn.SiLU()):
         super().__init__()
-        if dropout:
-            raise NotImplementedError(
-                f"dropout={dropout}: nn.Dropout(p=dropout) in ResBlock.out_layers (reference rho_diffusion/models/unet_v2.py:239) is not "
-                "built in the HIP engine - every shipped configuration (examples/*.json) trains with dropout 0")
+        if not (0.0 <= float(dropout) < 1.0):
+            raise ValueError(f"dropout probability has to be in [0, 1), got {dropout} (nn.Dropout at unet_v2.py:239)")
         self.act_code = activation_code(activation)
         self.channels = channels
         self.emb_channels = emb_channels
@@ -212,6 +212,9 @@ class UNet(nn.Module):
         if isinstance(activation, str):
             activation = registry.get("activations", activation)()
         self.act_code = activation_code(activation)
+        # key of the dropout masks (nn.Dropout(p) of every ResBlock, unet_v2.py:239, active in training mode): Philox, one stream per
+        # block; the reference draws from torch's global generator instead - the masks differ, their distribution does not
+        self.dropout_seed = int(os.environ.get("RHO_SEED", "777")) + int(os.environ.get("RANK", "0"))
 
         self.time_embed = nn.Sequential(nn.Linear(model_channels, embedding_dim), activation,
                                         nn.Linear(embedding_dim, embedding_dim))

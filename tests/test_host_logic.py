@@ -182,8 +182,9 @@ def test_unetv2_refuses_dropout_and_unbuilt_activations_naming_the_reference_lin
     from rho_diffusion_amd.models import UNet
     kw = dict(data_shape=[16, 16], in_channels=1, out_channels=1, model_channels=32, num_res_blocks=1, channel_mult=(1, 2),
               attention_resolutions=[], num_heads=2, dims=2)
-    with pytest.raises(NotImplementedError, match=r"unet_v2\.py:239"):
-        UNet(**kw, dropout=0.1)
+    with pytest.raises(ValueError, match=r"unet_v2\.py:239"):
+        UNet(**kw, dropout=1.0)
+    assert UNet(**kw, dropout=0.1).input_blocks[1][0].dropout == 0.1          # built since round 4 (Philox masks, tests/test_gpu_round4.py)
     for bad in ("PReLU", "Softmax", "LogSoftmax"):
         with pytest.raises(NotImplementedError, match=r"unet_v2\.py:518-519"):
             UNet(**kw, activation=bad)
