@@ -410,7 +410,7 @@ int rho_conv_nd_wgrad(const rho_conv_desc* desc, const void* dy, int64_t dy_widt
  * partial [taps][coutp][cin] (+ [coutp] channel sums) to a slab of its own in `ws`, and a second launch adds the slabs to dw / dbias
  * in slab order - the same values as the atomic flush up to the summation order, bit-identical run to run and across replicas.
  * ws: scratch of at least rho_conv_wgrad_workspace_bytes(desc, dy_width) bytes (170 - 340 MB per layer at BASELINE configs[2]);
- * costs one write + one read of it per launch (about +1.5 % per training step there). */
+ * costs one write + one read of it per launch (+2.1 % per training step there). */
 int rho_conv_nd_wgrad_ws(const rho_conv_desc* desc, const void* dy, int64_t dy_width, float* dw, float* dbias, void* ws,
                          int64_t ws_bytes, void* stream);
 int64_t rho_conv_wgrad_workspace_bytes(const rho_conv_desc* desc, int64_t dy_width);

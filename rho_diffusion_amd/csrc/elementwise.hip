@@ -435,6 +435,36 @@ extern "C" int rho_pack_input(const float* x, void* y, int dtype, int64_t n, int
 // so the engine's inference plans run them through the 1x1x1 path with these two HBM-rate helpers around it.
 // (kernel extents are template parameters: with run-time extents the tap -> (dz, dy, dx) divisions of the 32 columns cost 3000
 //  VALU instructions per position, 0.5 ms for 8.4 M positions instead of the 0.15 ms the bytes take)
+// Round 4: the 1-channel 3x3x3 case (also the GEMM-shaped backward of the stem / head in training plans) with FOUR threads per
+// position, one 16-byte piece (8 taps) each: consecutive threads write consecutive 16 bytes - 1 KB per wave store instead of four
+// 64-byte-strided stores per thread (1.5 -> ~3 TB/s on the 0.54 GB operand).
+__global__ __launch_bounds__(256) void k_im2col_333_c1(const float* __restrict__ x, bf16_raw* __restrict__ out, int D, int H, int W,
+                                                       int64_t total) {
+    const int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = gi >> 2;                        // output position
+    const int piece = (int)(gi & 3);
+    if (i >= total) return;
+    const int64_t S = (int64_t)D * H * W;
+    const int64_t n = i / S;
+    const int64_t ps = i - n * S;
+    const int w_ = (int)(ps % W), h_ = (int)((ps / W) % H), d_ = (int)(ps / ((int64_t)W * H));
+    const float* xs = x + n * S + ps;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int kk = piece * 8 + j;
+        float val = 0.0f;
+        if (kk < 27) {
+            const int dz = kk / 9 - 1, dy = (kk / 3) % 3 - 1, dx = kk % 3 - 1;
+            const int z = d_ + dz, y = h_ + dy, xx = w_ + dx;
+            if (z >= 0 && z < D && y >= 0 && y < H && xx >= 0 && xx < W) val = xs[((int64_t)dz * H + dy) * W + dx];
+        }
+        v[j] = val;
+    }
+    *reinterpret_cast<uint4*>(out + i * 32 + piece * 8) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                                                     pack_bf16x2(v[6], v[7]));
+}
+
 template <int KD, int KH, int KW>
 __global__ __launch_bounds__(256) void k_im2col_taps(const float* __restrict__ x, bf16_raw* __restrict__ out, int cin, int D, int H,
                                                      int W, int cpad, int64_t total) {
@@ -486,7 +516,10 @@ extern "C" int rho_im2col_taps(const float* x, void* out, int dtype, int64_t n, 
     if (cpad % 8 != 0 || cpad < cin * kd * kh * kw) return RHO_E_ALIGN;
     const int64_t total = n * d * h * w;
     dim3 grid((unsigned)((total + 255) / 256)), block(256);
-    if (kd == 3 && kh == 3 && kw == 3)
+    if (kd == 3 && kh == 3 && kw == 3 && cin == 1 && cpad == 32 && total < (1LL << 40))
+        hipLaunchKernelGGL(k_im2col_333_c1, dim3((unsigned)((total * 4 + 255) / 256)), block, 0, as_stream(stream), x, (bf16_raw*)out, (int)d,
+                           (int)h, (int)w, total);
+    else if (kd == 3 && kh == 3 && kw == 3)
         hipLaunchKernelGGL((k_im2col_taps<3, 3, 3>), grid, block, 0, as_stream(stream), x, (bf16_raw*)out, (int)cin, (int)d, (int)h, (int)w,
                            (int)cpad, total);
     else if (kd == 1 && kh == 3 && kw == 3)
