@@ -388,11 +388,11 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     #pragma unroll
             for (int s_ = 0; s_ < NACC; ++s_) asm volatile("" : "+v"(bv[s_]) : : "memory");
         };
+        constexpr int NIT2 = TAPSPLIT ? 64 : 16;        // (kk1 - kk0 is 128 or 32)
+#ifdef RHO_WGRAD_F32_OLDLOOP
+        // (round-3 form, kept for the A/B probe build: all reads of the next k-step, then the k-step's MFMAs back to back)
         float av0, bv0[NACC], av1, bv1[NACC];
         rd(kk0, av0, bv0);
-        constexpr int NIT2 = TAPSPLIT ? 64 : 16;        // (kk1 - kk0 is 128 or 32)
-        // (compile-time unrolled: the row offsets of every k-step fold into per-lane constants, and `between(IT)` - the DMA path's
-        //  share of the next tile's address set-up - lands between the MFMA groups)
         static_for<NIT2>([&](auto IT) {
             constexpr int it = decltype(IT)::value;
             const int kk = kk0 + 2 * it;
@@ -406,6 +406,37 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     #pragma unroll
             for (int s_ = 0; s_ < NACC; ++s_) acc[s_][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv1[s_], acc[s_][0], 0, 0, 0);
         });
+#else
+        // Round 4: a wave issues IN ORDER and has the SIMD to itself (one wave per SIMD: 144 KB of LDS), so the ~30 address / read /
+        // bookkeeping instructions of a k-step, scheduled as one run behind its five back-to-back MFMAs, only started to issue once the
+        // LAST of them had entered the pipe - 64 cycles of cover for >= 120 cycles of issue, the matrix pipe idle for the rest (the
+        // reduction alone ran at 0.62 of the f32 rate).  Now every MFMA is followed, in program order, by ONE operand read of k-step
+        // kk + 2 (three operand sets rotate) and a fifth of the other work, pinned by the data-dependence fence in front of the next
+        // MFMA (the MFMA comes after it through its operands, the reads issued before it stay before it through the memory clobber)
+        // and a scheduling barrier behind the group: each group issues inside its own MFMA's 64 cycles.
+        float av[3], bv[3][NACC];
+        rd(kk0, av[0], bv[0]);
+        rd(min(kk0 + 1, kk1 - 1), av[1], bv[1]);
+        static_for<2 * NIT2>([&](auto KS) {
+            constexpr int ks = decltype(KS)::value;
+            constexpr int cur = ks % 3, nn = (ks + 2) % 3;
+            const int kn = min(kk0 + ks + 2, kk1 - 1);               // (past the end: a harmless re-read of the last k-step)
+            const int pp = 2 * kn + half;
+            const int pw = pp & (p.TW - 1), ph = (pp >> p.lgTW) & (p.TH - 1), pd = pp >> (p.lgTW + p.lgTH);
+            const int xr = ((pd * p.IH + ph * p.sh) * p.IW + pw * p.sw) * XP;
+    #pragma unroll
+            for (int s_ = 0; s_ < NACC; ++s_) {
+                asm volatile("" : "+v"(av[cur]), "+v"(bv[cur][s_]) : : "memory");
+                acc[s_][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur], bv[cur][s_], acc[s_][0], 0, 0, 0);
+                if (s_ == 0) av[nn] = *reinterpret_cast<const float*>(dyt_ + pp * DYP + ((col * 4) ^ dy_swz(pp)));
+                bv[nn][s_] = *reinterpret_cast<const float*>(halo_ + xr + toff2[s_]);
+                if constexpr ((ks & 1) == 0) {
+                    if (s_ == NACC / 2) between(std::integral_constant<int, ks / 2>{});
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+#endif
     };
     if constexpr (DMA) {
         // ------------------------------------------------------------------ double-buffered LDS tiles filled by LDS-DMA
