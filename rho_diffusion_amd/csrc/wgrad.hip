@@ -138,7 +138,8 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     char* const halo = smem;                          // MAXP*64 rows (rows >= NP are written with zeros, never read)
     char* const dyt = smem + (size_t)MAXP * 64 * XP;  // (PIPE: buffer b = [halo | dY] at smem + b * BUF)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: keeps the tap offsets in scalar registers
     const int piece = tid & 3;
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  The cout-tile x cin-chunk workgroups of one position
     // slab read the same dY tile / X rows: with the plain 3-D grid the second chunk of a slab ran rounds later on whatever XCD and
@@ -440,20 +441,174 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     };
     if constexpr (DMA) {
         // ------------------------------------------------------------------ double-buffered LDS tiles filled by LDS-DMA
-        // Phase of tile t: (1) issue the 18 global_load_lds_dwordx4 of tile t+1 into the other buffer (addresses were computed
-        // during phase t-1), (2) compute the addresses of tile t+2 (pure VALU, blended into the MFMAs by the compiler),
-        // (3) 16 k-steps of MFMAs out of this tile's buffer, (4) __syncthreads(): its vmcnt(0) retires the DMA, its barrier
-        // publishes the buffer.  No staging registers, no ds_write, no serial load-wait / write / set-up phase per tile.
-        // The LDS image is lane-linear (16 bytes x tid per 4 KB slot), which is exactly the halo layout (64-byte rows, 4 pieces)
-        // and the dY layout (128-byte rows, 8 pieces); the dY half-swap of rows with bit 1 set and the zero fill of padding /
-        // out-of-range rows are applied on the SOURCE side (swapped channel piece; a zero page in the code object).
+        // Phase of tile t: the 18 global_load_lds_dwordx4 of tile t+1 (into the other buffer; their addresses were computed during phase
+        // t-1), the address set-up of tile t+2 and 16 k-steps of MFMAs out of this tile's buffer, then __syncthreads(): a vmcnt(0) in
+        // front of it retires the DMA, the barrier publishes the buffer.  No staging registers, no ds_write, no serial load-wait /
+        // write / set-up phase per tile.  The LDS image is lane-linear (16 bytes x tid per 4 KB slot), which is exactly the halo layout
+        // (64-byte rows, 4 pieces) and the dY layout (128-byte rows, 8 pieces); the dY half-swap of rows with bit 1 set and the zero
+        // fill of padding / out-of-range rows are applied on the SOURCE side (swapped channel piece; a zero page in the code object).
+        //
+        // Round 4: ONE wave per SIMD issues IN ORDER, so whatever sits between two MFMAs in program order delays the second one.  The
+        // compiler's own schedule ran the 18 DMAs as one burst at the top of the phase, the slot addresses as exec-masked branches with
+        // 64-bit multiplies (~25 instructions per slot) and the transposing reads in runs of 12 - 16 between groups of MFMAs: removing
+        // the address work alone returned 15 % of the launch, the DMAs 11 % (timing probes).  Now (a) a slot address is a
+        // wave-uniform 64-bit tile base + a per-lane 32-bit offset fixed for the launch, its validity one bit of a per-tile mask (only
+        // the first / last tile of a dimension has padding or overhang: per-lane masks for those six cases are built once) - 6 VALU per
+        // slot, no branch; (b) the tile walk is incremental (no divisions); (c) every MFMA is followed, in program order, by its share
+        // of the k-step's reads, of the DMAs and of the set-up, and a scheduling barrier pins that order.
         const int dsw = dpiece ^ (((tid >> 4) & 1) << 2);                  // channel piece this thread FETCHES for its dY slots
         const bool dsw_ok = (co0 + dsw * PE) < p.dyw;
-        const char* const dsrc2 = p.dy + (size_t)(dsw_ok ? co0 + dsw * PE : 0) * sizeof(T);
         const char* const zpage = reinterpret_cast<const char*>(g_wgrad_zero);
+        const char* const srcu = (c < p.c1) ? p.x1 + (size_t)c * sizeof(T) : p.x2 + (size_t)(c - p.c1) * sizeof(T);   // wave-uniform
+        const char* srcu2 = srcu;
+        if (has2) {
+            const int cb = c + CK;
+            srcu2 = (cb < p.c1) ? p.x1 + (size_t)cb * sizeof(T) : p.x2 + (size_t)(cb - p.c1) * sizeof(T);
+        }
+        // per-lane byte offset of every slot from the tile's base, and the validity masks (bit i: halo slot i, bit 16 + i: dY slot i)
+        unsigned xoff[MAXP], doff[8];
+        unsigned mlo[3], mhi[3], mvalid = dsw_ok ? 0x00FF0000u : 0u;
+        {
+            const int gdL = (p.tiles_d - 1) * p.TD - (KD / 2), ghL = (p.tiles_h - 1) * p.TH * p.sh - p.pad_h, gwL = (p.tiles_w - 1) * p.TW * p.sw - p.pad_w;
+            const int odL = p.Do - (p.tiles_d - 1) * p.TD, ohL = p.Ho - (p.tiles_h - 1) * p.TH, owL = p.Wo - (p.tiles_w - 1) * p.TW;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { mlo[k] = 0xFFFFFFFFu; mhi[k] = 0xFFFFFFFFu; }
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) {
+                const int id = sdec[i] >> 20, ih = (sdec[i] >> 10) & 1023, iw = sdec[i] & 1023;
+                const unsigned bit = 1u << i;
+                if (sdec[i] >= 0) mvalid |= bit;
+                if (id < (KD / 2)) mlo[0] &= ~bit;
+                if (ih < p.pad_h) mlo[1] &= ~bit;
+                if (iw < p.pad_w) mlo[2] &= ~bit;
+                if (gdL + id >= p.D) mhi[0] &= ~bit;
+                if (ghL + ih >= p.H) mhi[1] &= ~bit;
+                if (gwL + iw >= p.W) mhi[2] &= ~bit;
+                const int cs_i = (PAIRC && i >= 4 && i < 8) ? cs2 : cs;
+                xoff[i] = (unsigned)srel[i] * (unsigned)(cs_i * (int)sizeof(T)) + (unsigned)piece * 16u;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int pd = ddec[i] >> 20, ph = (ddec[i] >> 10) & 1023, pw = ddec[i] & 1023;
+                const unsigned bit = 0x10000u << i;
+                if (pd >= odL) mhi[0] &= ~bit;
+                if (ph >= ohL) mhi[1] &= ~bit;
+                if (pw >= owL) mhi[2] &= ~bit;
+                doff[i] = (unsigned)drel[i] * (unsigned)(p.dyw * (int)sizeof(T)) + (unsigned)(dsw_ok ? co0 + dsw * PE : 0) * (unsigned)sizeof(T);
+            }
+        }
+        // the tile whose addresses are being set up (wave-uniform: scalar unit)
+        int a_n = 0, a_d = 0, a_h = 0, a_w = 0, a_tl = tile0;
+        const char* xt = srcu;
+        const char* xt2 = srcu2;
+        const char* dt = p.dy;
+        unsigned mk = 0;
+        auto tile_first = [&](int tl) {
+            int t = tl;
+            a_w = t % p.tiles_w; t /= p.tiles_w;
+            a_h = t % p.tiles_h; t /= p.tiles_h;
+            a_d = t % p.tiles_d;
+            a_n = t / p.tiles_d;
+            a_tl = tl;
+        };
+        auto tile_next = [&]() {                                           // (past the end: stays on the last tile - a harmless re-read)
+            // branch-free (selects on the scalar unit): a branch here would split the k-loop's basic block and with it the schedule
+            const bool adv = a_tl + 1 < tile1;
+            const int w1 = a_w + 1;
+            const bool cw = w1 == p.tiles_w;
+            const int h1 = a_h + (cw ? 1 : 0);
+            const bool ch = h1 == p.tiles_h;
+            const int d1 = a_d + (ch ? 1 : 0);
+            const bool cd = d1 == p.tiles_d;
+            a_tl += adv ? 1 : 0;
+            a_n = adv ? a_n + (cd ? 1 : 0) : a_n;
+            a_d = adv ? (cd ? 0 : d1) : a_d;
+            a_h = adv ? (ch ? 0 : h1) : a_h;
+            a_w = adv ? (cw ? 0 : w1) : a_w;
+        };
+        auto tile_bases = [&]() {
+            const int od0 = a_d * p.TD, oh0 = a_h * p.TH, ow0 = a_w * p.TW;
+            const int gd = od0 - (KD / 2), gh = oh0 * p.sh - p.pad_h, gw = ow0 * p.sw - p.pad_w;
+            const int b = ((a_n * p.D + gd) * p.H + gh) * p.W + gw;
+            const int db = ((a_n * p.Do + od0) * p.Ho_out + oh0 * p.oy_mul + p.oy_add) * p.Wo_out + ow0 * p.ox_mul + p.ox_add;
+            xt = srcu + (ptrdiff_t)b * (ptrdiff_t)(cs * (int)sizeof(T));
+            if constexpr (PAIRC) xt2 = srcu2 + (ptrdiff_t)b * (ptrdiff_t)(cs2 * (int)sizeof(T));
+            dt = p.dy + (ptrdiff_t)db * (ptrdiff_t)(p.dyw * (int)sizeof(T));
+            // (pure arithmetic with its only use in the NEXT iteration: without a pin the compiler sinks it - and the slot addresses
+            //  below - out of the k-loop into the latch block, a serial run again)
+            asm volatile("" : "+s"(xt), "+s"(dt));
+            if constexpr (PAIRC) asm volatile("" : "+s"(xt2));
+        };
+        auto tile_mask = [&]() {
+            unsigned m = mvalid;
+            m &= (a_d == 0) ? mlo[0] : 0xFFFFFFFFu;
+            m &= (a_h == 0) ? mlo[1] : 0xFFFFFFFFu;
+            m &= (a_w == 0) ? mlo[2] : 0xFFFFFFFFu;
+            m &= (a_d == p.tiles_d - 1) ? mhi[0] : 0xFFFFFFFFu;
+            m &= (a_h == p.tiles_h - 1) ? mhi[1] : 0xFFFFFFFFu;
+            m &= (a_w == p.tiles_w - 1) ? mhi[2] : 0xFFFFFFFFu;
+            mk = m;
+            asm volatile("" : "+v"(mk));
+        };
         const char* ax[MAXP];
         const char* ad[8];
-        int od_lim = 0, oh_lim = 0, ow_lim = 0;
+        auto addr_slot = [&](auto SL) {                                    // global source of slot SL of the tile set up last
+            constexpr int sl = decltype(SL)::value;
+            if constexpr (sl < MAXP) {
+                const char* a = ((PAIRC && sl >= 4 && sl < 8) ? xt2 : xt) + xoff[sl];
+                ax[sl] = ((mk >> sl) & 1u) ? a : zpage;
+                asm volatile("" : "+v"(ax[sl]));
+            } else {
+                constexpr int i = sl - MAXP;
+                const char* a = dt + doff[i];
+                ad[i] = ((mk >> (16 + i)) & 1u) ? a : zpage;
+                asm volatile("" : "+v"(ad[i]));
+            }
+        };
+        constexpr int NSLOT = MAXP + 8;
+        // LDS-DMA as inline asm (cdna_hip_programming.md 5.7): through the builtin the compiler treats the DMA as a store that may
+        // alias every later ds_read and drains vmcnt(0) in front of the first fragment read of the phase - the whole HBM -> LDS
+        // latency serial again.  As asm it is invisible to the compiler's wait bookkeeping; the one wait it needs (all of them
+        // landed before the buffer is published) is the explicit vmcnt(0) in front of the end-of-phase barrier below.
+        const unsigned ldsw = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)wave * 1024u);
+        auto glds16 = [&](const char* gsrc, unsigned lds_dst) {            // wave-uniform LDS base + 16 bytes x lane
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+        };
+        auto dma_slot = [&](auto SL, int wb) {
+            constexpr int sl = decltype(SL)::value;
+            if constexpr (sl < MAXP) glds16(ax[sl], ldsw + wb + sl * 4096);
+            else glds16(ad[sl - MAXP], ldsw + wb + XBUF + (sl - MAXP) * 4096);
+        };
+        // What rides behind MFMA g of the G a wave issues per tile: the DMAs over the first 9/16 of the phase (so that the last of them
+        // has the rest of it to land), then - after the three scalar / mask pieces of the tile walk - the slot addresses of tile t+2
+        // (slot s only after its DMA of tile t+1 has been issued: it overwrites the address register).
+        auto filler = [&](auto GI, auto GN, int wb) {
+            constexpr int g = decltype(GI)::value, G = decltype(GN)::value;
+            constexpr int GD = (G * 9 + 15) / 16;
+            constexpr int GA0 = G >= 16 ? 6 : 0;
+            static_for<NSLOT>([&](auto SL) {
+                if constexpr ((decltype(SL)::value * GD) / NSLOT == g) dma_slot(SL, wb);
+            });
+            if constexpr (g == 0) tile_next();
+            if constexpr (g == (GA0 >= 6 ? 2 : 0)) tile_bases();
+            if constexpr (g == (GA0 >= 6 ? 4 : 0)) tile_mask();
+            static_for<NSLOT>([&](auto SL) {
+                if constexpr (GA0 + (decltype(SL)::value * (G - GA0)) / NSLOT == g) addr_slot(SL);
+            });
+        };
+        using I0_ = std::integral_constant<int, 0>;
+        using I1_ = std::integral_constant<int, 1>;
+        if (tile0 < tile1) {
+            tile_first(tile0);
+            tile_bases();
+            tile_mask();
+            static_for<NSLOT>([&](auto SL) { addr_slot(SL); });
+            filler(I0_{}, I1_{}, 0);                        // all DMAs of the first tile, then the addresses of the second
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
         // LDS row offset of position pp of the tile = sum over the set bits k of pp of C_k (the pw / ph / pd fields are disjoint bit
         // ranges of pp): xrow_of(j, tt) = xb[tt] + sum of kc[] over the bits of j.  kc[] is wave-uniform (scalar registers), so the
         // 32 per-k-step row offsets of the single-buffered path shrink to two vector registers.
@@ -466,115 +621,60 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
         int xb[2];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) xb[tt] = xrow_of(0, tt);          // j = 0: the lane's part (+ the wave's k-step base if !TAPSPLIT)
-
-        auto decode2 = [&](int tl) {                                       // wave-uniform part (scalar unit)
-            decode(tl);
-            od_lim = p.Do - (gd_base + KD / 2);
-            oh_lim = p.Ho - (gh_base + p.pad_h) / p.sh;
-            ow_lim = p.Wo - (gw_base + p.pad_w) / p.sw;
-        };
-        auto addr_slot = [&](auto SL) {                                    // global source of slot SL of the tile last decoded
-            constexpr int sl = decltype(SL)::value;
-            if constexpr (sl < MAXP) {
-                constexpr int i = sl;
-                const int id = sdec[i] >> 20, ih = (sdec[i] >> 10) & 1023, iw = sdec[i] & 1023;
-                const bool ok = (sdec[i] >= 0) & ((unsigned)(gd_base + id) < (unsigned)p.D) & ((unsigned)(gh_base + ih) < (unsigned)p.H) &
-                                ((unsigned)(gw_base + iw) < (unsigned)p.W);
-                if (PAIRC && i >= 4 && i < 8)          // (f32 1x1x1 pair mode: slots 4 .. 7 = the second chunk)
-                    ax[i] = ok ? src2 + (size_t)(base + srel[i]) * cs2 * sizeof(T) : zpage;
-                else
-                    ax[i] = ok ? src + (size_t)(base + srel[i]) * cs * sizeof(T) : zpage;
-            } else {
-                constexpr int i = sl - MAXP;
-                const int pd = ddec[i] >> 20, ph = (ddec[i] >> 10) & 1023, pw = ddec[i] & 1023;
-                const bool ok = (pd < od_lim) & (ph < oh_lim) & (pw < ow_lim) & dsw_ok;
-                ad[i] = ok ? dsrc2 + (size_t)(dbase + drel[i]) * p.dyw * sizeof(T) : zpage;
-            }
-        };
-        constexpr int NSLOT = MAXP + 8;
-        auto addresses = [&](int tl) {
-            decode2(tl);
-            static_for<NSLOT>([&](auto SL) { addr_slot(SL); });
-        };
-        // LDS-DMA as inline asm (cdna_hip_programming.md 5.7): through the builtin the compiler treats the DMA as a store that may
-        // alias every later ds_read and drains vmcnt(0) in front of the first fragment read of the phase - the whole HBM -> LDS
-        // latency serial again.  As asm it is invisible to the compiler's wait bookkeeping; the one wait it needs (all of them
-        // landed before the buffer is published) is the explicit vmcnt(0) in front of the end-of-phase barrier below.
-        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-        auto glds16 = [&](const char* gsrc, unsigned lds_dst) {
-            unsigned keep;
-            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
-        };
-        auto dma = [&](int wb) {                                           // wave-uniform LDS base + 16 bytes x lane
-            static_for<MAXP>([&](auto I) {
-                constexpr int i = decltype(I)::value;
-                glds16(ax[i], lds0 + wb + wave * 1024 + i * 4096);
-            });
-            static_for<8>([&](auto I) {
-                constexpr int i = decltype(I)::value;
-                glds16(ad[i], lds0 + wb + XBUF + wave * 1024 + i * 4096);
-            });
-        };
-        if (tile0 < tile1) {
-            addresses(tile0);
-            dma(0);
-            addresses(min(tile0 + 1, tile1 - 1));
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
         for (int tl = tile0; tl < tile1; ++tl) {
             const int rdb = ((tl - tile0) & 1) * BUF, wrb = BUF - rdb;
-#ifdef RHO_PROBE_F32_NODMA
-            if constexpr (IS_BF16)
-#endif
-            dma(wrb);                                       // tile tl + 1 (past the end: a harmless re-read of the last tile)
-            decode2(min(tl + 2, tile1 - 1));                // its slot addresses are dealt into the k-steps below
             if constexpr (IS_BF16) {
-            int tob[TPW], ab[MT];
+                // lane bases of the transposing reads of this buffer: halo (per tap and half), dY (per cout half)
+                int vt[TPW][2], ab[MT];
 #pragma unroll
-                for (int ti = 0; ti < TPW; ++ti) tob[ti] = tapoff[ti] + rdb;
+                for (int ti = 0; ti < TPW; ++ti)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) vt[ti][tt] = xb[tt] + (tapoff[ti] + rdb);
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi) ab[mi] = arow[mi] + rdb + XBUF;
-                // Fragments of k-step j + 1 are read from LDS BEFORE the 14 MFMAs of k-step j are issued (two register sets): with one
-                // wave per SIMD nothing else covers the ~100+ cycles of a transposing read.
-                uint4 fa[2][MT], fb[2][TPW];
-                auto rd_frags = [&](auto J) {
-                    constexpr int j = decltype(J)::value;
-                    constexpr int s_ = j & 1;
-                    const int sj = ((j & 1) ? kc[0] : 0) + ((j & 2) ? kc[1] : 0) + ((j & 4) ? kc[2] : 0) + ((j & 8) ? kc[3] : 0);   // scalar
-#pragma unroll
-                    for (int mi = 0; mi < MT; ++mi) fa[s_][mi] = tr_frag(smem, ab[mi] + j * 16 * DYP, ab[mi] + (j * 16 + 4) * DYP);
-#pragma unroll
-                    for (int ti = 0; ti < TPW; ++ti) fb[s_][ti] = tr_frag(smem, xb[0] + (tob[ti] + sj), xb[1] + (tob[ti] + sj));
+                // Fragments of k-step j + 1 are read from LDS while the 14 MFMAs of k-step j issue (two register sets): with one
+                // wave per SIMD nothing else covers the ~100+ cycles of a transposing read.  Read r of a k-step: the dY halves first
+                // (every MFMA of the k-step needs them), then the taps in the order the MFMAs consume them.
+                constexpr int NRD = 2 * (MT + TPW), NMM = TPW * MT;
+                s16x4_t fa[2][MT][2], fb[2][TPW][2];
+                auto rd_one = [&](auto J, auto R) {
+                    constexpr int j = decltype(J)::value, r = decltype(R)::value, s_ = j & 1, h = r & 1;
+                    if constexpr (r < 2 * MT) {
+                        fa[s_][r >> 1][h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4_t*)(smem + (ab[r >> 1] + (j * 16 + 4 * h) * DYP)));
+                    } else {
+                        constexpr int ti = (r - 2 * MT) >> 1;
+                        const int sj = ((j & 1) ? kc[0] : 0) + ((j & 2) ? kc[1] : 0) + ((j & 4) ? kc[2] : 0) + ((j & 8) ? kc[3] : 0);   // scalar
+                        fb[s_][ti][h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(smem + (vt[ti][h] + sj)));
+                    }
                 };
-                rd_frags(std::integral_constant<int, 0>{});
+                auto frag = [&](const s16x4_t (&f)[2]) {
+                    uint4 u;
+                    u.x = (uint32_t)(uint16_t)f[0][0] | ((uint32_t)(uint16_t)f[0][1] << 16);
+                    u.y = (uint32_t)(uint16_t)f[0][2] | ((uint32_t)(uint16_t)f[0][3] << 16);
+                    u.z = (uint32_t)(uint16_t)f[1][0] | ((uint32_t)(uint16_t)f[1][1] << 16);
+                    u.w = (uint32_t)(uint16_t)f[1][2] | ((uint32_t)(uint16_t)f[1][3] << 16);
+                    return u;
+                };
+                static_for<NRD>([&](auto R) { rd_one(I0_{}, R); });
                 static_for<NKS>([&](auto J) {
                     constexpr int j = decltype(J)::value;
-                    if constexpr (j + 1 < NKS) rd_frags(std::integral_constant<int, j + 1>{});
-#pragma unroll
-                    for (int ti = 0; ti < TPW; ++ti)
-#pragma unroll
-                        for (int mi = 0; mi < MT; ++mi) mma_step<T>(fa[j & 1][mi], fb[j & 1][ti], acc[ti][mi]);
-                    // this k-step's share of the address set-up of tile tl + 2 (pure VALU, hidden under the MFMAs)
-                    static_for<NSLOT>([&](auto SL) {
-                        if constexpr ((decltype(SL)::value * NKS) / NSLOT == j) addr_slot(SL);
+                    static_for<NMM>([&](auto M) {
+                        constexpr int m = decltype(M)::value, ti = m / MT, mi = m % MT;
+                        mma_step<T>(frag(fa[j & 1][mi]), frag(fb[j & 1][ti]), acc[ti][mi]);
+                        if constexpr (j + 1 < NKS) {
+                            static_for<NRD>([&](auto R) {
+                                if constexpr ((decltype(R)::value * NMM) / NRD == m) rd_one(std::integral_constant<int, j + 1>{}, R);
+                            });
+                        }
+                        filler(std::integral_constant<int, j * NMM + m>{}, std::integral_constant<int, NKS * NMM>{}, wrb);
+                        __builtin_amdgcn_sched_barrier(0);
                     });
                 });
             } else {
-                // exact f32: the same double-buffered DMA staging, the f32 reduction (two taps / chunks per MFMA) on buffer rdb;
-                // the address set-up of tile tl + 2 follows it (pure VALU)
-#ifndef RHO_PROBE_F32_NOMMA      /* timing probes (wrong results): -DRHO_PROBE_F32_NOMMA skips the reduction, _NODMA the staging */
+                // exact f32: the same double-buffered DMA staging, the f32 reduction (two taps / chunks per MFMA) on buffer rdb
                 constexpr int NIT2_ = TAPSPLIT ? 64 : 16;
-                f32_tile(smem + rdb, smem + rdb + XBUF, [&](auto IT) {
-                    static_for<NSLOT>([&](auto SL) {
-                        if constexpr ((decltype(SL)::value * NIT2_) / NSLOT == decltype(IT)::value) addr_slot(SL);
-                    });
-                });
-#else
-                static_for<NSLOT>([&](auto SL) { addr_slot(SL); });
-#endif
+                f32_tile(smem + rdb, smem + rdb + XBUF, [&](auto IT) { filler(IT, std::integral_constant<int, NIT2_>{}, wrb); });
             }
             if (do_bias) {
                 // bias gradient = channel sums of dY: this thread's 8 pieces of the tile just reduced (LDS slot tid * 16 of
