@@ -103,7 +103,9 @@ __device__ __forceinline__ uint4 tr_frag(const char* lds, int r0, int r1) {
 
 // PRE: the folded GroupNorm affine + SiLU is applied while the halo is staged (p.pre_a != NULL); a compile-time switch so that
 // the common training path (input materialised by rho_gn_apply, PRE = false) keeps its staging code free of branches.
-template <typename T, int KD, int KH, int KW, int MAXP, bool PRE>
+// GEO = 1: the tile geometry is a compile-time constant (4 x 8 x 8 output positions, 10 x 10 halo rows, stride 1 - every stride-1
+// 3x3x3 layer of the 3-D configurations): the LDS offsets of the k-steps become immediates of the transposing reads.
+template <typename T, int KD, int KH, int KW, int MAXP, bool PRE, int GEO = 0>
 __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CK = ET<T>::CK;
@@ -380,34 +382,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     #pragma unroll
             for (int s_ = 0; s_ < NACC; ++s_) bv[s_] = *reinterpret_cast<const float*>(halo_ + xr + toff2[s_]);
         };
-        // MFMA intrinsics carry no chain, so the scheduler sinks the reads of the NEXT k-step below the current MFMAs and then waits for
-        // them right in front of their use (measured: the reduction alone ran at 62 % of the f32 MFMA rate).  As in k_conv: an empty
-        // volatile asm that passes the operands the next MFMAs use (data dependence) with a memory clobber pins the source order -
-        // the reads of k-step kk + 1 are issued, THEN the MFMAs of k-step kk.
-        auto pin = [&](float& av, float (&bv)[NACC]) {
-            asm volatile("" : "+v"(av) : : "memory");
-    #pragma unroll
-            for (int s_ = 0; s_ < NACC; ++s_) asm volatile("" : "+v"(bv[s_]) : : "memory");
-        };
         constexpr int NIT2 = TAPSPLIT ? 64 : 16;        // (kk1 - kk0 is 128 or 32)
-#ifdef RHO_WGRAD_F32_OLDLOOP
-        // (round-3 form, kept for the A/B probe build: all reads of the next k-step, then the k-step's MFMAs back to back)
-        float av0, bv0[NACC], av1, bv1[NACC];
-        rd(kk0, av0, bv0);
-        static_for<NIT2>([&](auto IT) {
-            constexpr int it = decltype(IT)::value;
-            const int kk = kk0 + 2 * it;
-            rd(kk + 1, av1, bv1);
-            pin(av0, bv0);
-    #pragma unroll
-            for (int s_ = 0; s_ < NACC; ++s_) acc[s_][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv0[s_], acc[s_][0], 0, 0, 0);
-            between(IT);
-            rd(min(kk + 2, kk1 - 1), av0, bv0);
-            pin(av1, bv1);
-    #pragma unroll
-            for (int s_ = 0; s_ < NACC; ++s_) acc[s_][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv1[s_], acc[s_][0], 0, 0, 0);
-        });
-#else
         // Round 4: a wave issues IN ORDER and has the SIMD to itself (one wave per SIMD: 144 KB of LDS), so the ~30 address / read /
         // bookkeeping instructions of a k-step, scheduled as one run behind its five back-to-back MFMAs, only started to issue once the
         // LAST of them had entered the pipe - 64 cycles of cover for >= 120 cycles of issue, the matrix pipe idle for the rest (the
@@ -437,7 +412,6 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         });
-#endif
     };
     if constexpr (DMA) {
         // ------------------------------------------------------------------ double-buffered LDS tiles filled by LDS-DMA
@@ -511,39 +485,69 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
             a_n = t / p.tiles_d;
             a_tl = tl;
         };
-        auto tile_next = [&]() {                                           // (past the end: stays on the last tile - a harmless re-read)
-            // branch-free (selects on the scalar unit): a branch here would split the k-loop's basic block and with it the schedule
-            const bool adv = a_tl + 1 < tile1;
-            const int w1 = a_w + 1;
-            const bool cw = w1 == p.tiles_w;
-            const int h1 = a_h + (cw ? 1 : 0);
-            const bool ch = h1 == p.tiles_h;
-            const int d1 = a_d + (ch ? 1 : 0);
-            const bool cd = d1 == p.tiles_d;
-            a_tl += adv ? 1 : 0;
-            a_n = adv ? a_n + (cd ? 1 : 0) : a_n;
-            a_d = adv ? (cd ? 0 : d1) : a_d;
-            a_h = adv ? (ch ? 0 : h1) : a_h;
-            a_w = adv ? (cw ? 0 : w1) : a_w;
+        // (branch-free - selects on the scalar unit: a branch would split the k-loop's basic block and with it the schedule - and in
+        //  pieces small enough to ride behind one MFMA each; past the end the walk stays on the last tile: a harmless re-read)
+        // (the carries as scalar compare + select in asm - the compiler turns a boolean into an integer on the vector unit - which also
+        //  pins every piece where it is written)
+        int t_cw = 0, t_ch = 0;
+        auto s_eq = [](int a, int b) { int r; asm volatile("s_cmp_eq_u32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(a), "s"(b) : "scc"); return r; };
+        auto s_lt = [](int a, int b) { int r; asm volatile("s_cmp_lt_i32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(a), "s"(b) : "scc"); return r; };
+        auto tile_next_w = [&]() {
+            const int adv = s_lt(a_tl + 1, tile1);
+            const int w1 = a_w + adv;                      // (not advancing: a_w < tiles_w stays, no carry)
+            t_cw = s_eq(w1, p.tiles_w);
+            a_tl += adv;
+            a_w = w1 - t_cw * p.tiles_w;
+            asm volatile("" : "+s"(a_w), "+s"(a_tl));
         };
-        auto tile_bases = [&]() {
-            const int od0 = a_d * p.TD, oh0 = a_h * p.TH, ow0 = a_w * p.TW;
-            const int gd = od0 - (KD / 2), gh = oh0 * p.sh - p.pad_h, gw = ow0 * p.sw - p.pad_w;
-            const int b = ((a_n * p.D + gd) * p.H + gh) * p.W + gw;
-            const int db = ((a_n * p.Do + od0) * p.Ho_out + oh0 * p.oy_mul + p.oy_add) * p.Wo_out + ow0 * p.ox_mul + p.ox_add;
-            xt = srcu + (ptrdiff_t)b * (ptrdiff_t)(cs * (int)sizeof(T));
-            if constexpr (PAIRC) xt2 = srcu2 + (ptrdiff_t)b * (ptrdiff_t)(cs2 * (int)sizeof(T));
-            dt = p.dy + (ptrdiff_t)db * (ptrdiff_t)(p.dyw * (int)sizeof(T));
+        auto tile_next_h = [&]() {
+            const int h1 = a_h + t_cw;
+            t_ch = s_eq(h1, p.tiles_h);
+            a_h = h1 - t_ch * p.tiles_h;
+            asm volatile("" : "+s"(a_h));
+        };
+        auto tile_next_d = [&]() {
+            const int d1 = a_d + t_ch;
+            const int cd = s_eq(d1, p.tiles_d);
+            a_n += cd;
+            a_d = d1 - cd * p.tiles_d;
+            asm volatile("" : "+s"(a_n), "+s"(a_d));
+        };
+        int t_b = 0, t_db = 0;
+        auto tile_base_x0 = [&]() {
+            const int gd = a_d * p.TD - (KD / 2), gh = a_h * p.TH * p.sh - p.pad_h, gw = a_w * p.TW * p.sw - p.pad_w;
+            t_b = ((a_n * p.D + gd) * p.H + gh) * p.W + gw;
+            asm volatile("" : "+s"(t_b));
+        };
+        auto tile_base_x1 = [&]() {
+            xt = srcu + (ptrdiff_t)t_b * (ptrdiff_t)(cs * (int)sizeof(T));
             // (pure arithmetic with its only use in the NEXT iteration: without a pin the compiler sinks it - and the slot addresses
             //  below - out of the k-loop into the latch block, a serial run again)
-            asm volatile("" : "+s"(xt), "+s"(dt));
-            if constexpr (PAIRC) asm volatile("" : "+s"(xt2));
+            asm volatile("" : "+s"(xt));
+            if constexpr (PAIRC) {
+                xt2 = srcu2 + (ptrdiff_t)t_b * (ptrdiff_t)(cs2 * (int)sizeof(T));
+                asm volatile("" : "+s"(xt2));
+            }
         };
-        auto tile_mask = [&]() {
+        auto tile_base_dy0 = [&]() {
+            t_db = ((a_n * p.Do + a_d * p.TD) * p.Ho_out + a_h * p.TH * p.oy_mul + p.oy_add) * p.Wo_out + a_w * p.TW * p.ox_mul + p.ox_add;
+            asm volatile("" : "+s"(t_db));
+        };
+        auto tile_base_dy1 = [&]() {
+            dt = p.dy + (ptrdiff_t)t_db * (ptrdiff_t)(p.dyw * (int)sizeof(T));
+            asm volatile("" : "+s"(dt));
+        };
+        unsigned t_m = 0;
+        auto tile_mask0 = [&]() {
             unsigned m = mvalid;
             m &= (a_d == 0) ? mlo[0] : 0xFFFFFFFFu;
             m &= (a_h == 0) ? mlo[1] : 0xFFFFFFFFu;
             m &= (a_w == 0) ? mlo[2] : 0xFFFFFFFFu;
+            t_m = m;
+            asm volatile("" : "+v"(t_m));
+        };
+        auto tile_mask1 = [&]() {
+            unsigned m = t_m;
             m &= (a_d == p.tiles_d - 1) ? mhi[0] : 0xFFFFFFFFu;
             m &= (a_h == p.tiles_h - 1) ? mhi[1] : 0xFFFFFFFFu;
             m &= (a_w == p.tiles_w - 1) ? mhi[2] : 0xFFFFFFFFu;
@@ -571,10 +575,11 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
         // latency serial again.  As asm it is invisible to the compiler's wait bookkeeping; the one wait it needs (all of them
         // landed before the buffer is published) is the explicit vmcnt(0) in front of the end-of-phase barrier below.
         const unsigned ldsw = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)wave * 1024u);
+        // M0 (the DMA's LDS base) is left as set: nothing the compiler emits for this kernel reads M0 (no LDS-direct / GWS / movrel;
+        // tests/test_cabi.py checks the disassembly of the built library for exactly that), and the save / restore pair around every
+        // DMA was 36 scalar instructions per tile in MFMA gaps that have room for seven.
         auto glds16 = [&](const char* gsrc, unsigned lds_dst) {            // wave-uniform LDS base + 16 bytes x lane
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory");
         };
         auto dma_slot = [&](auto SL, int wb) {
             constexpr int sl = decltype(SL)::value;
@@ -582,18 +587,24 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
             else glds16(ad[sl - MAXP], ldsw + wb + XBUF + (sl - MAXP) * 4096);
         };
         // What rides behind MFMA g of the G a wave issues per tile: the DMAs over the first 9/16 of the phase (so that the last of them
-        // has the rest of it to land), then - after the three scalar / mask pieces of the tile walk - the slot addresses of tile t+2
+        // has the rest of it to land), then - after the nine scalar / mask pieces of the tile walk - the slot addresses of tile t+2
         // (slot s only after its DMA of tile t+1 has been issued: it overwrites the address register).
         auto filler = [&](auto GI, auto GN, int wb) {
             constexpr int g = decltype(GI)::value, G = decltype(GN)::value;
             constexpr int GD = (G * 9 + 15) / 16;
-            constexpr int GA0 = G >= 16 ? 6 : 0;
+            constexpr int GA0 = G >= 16 ? 10 : 0;
             static_for<NSLOT>([&](auto SL) {
                 if constexpr ((decltype(SL)::value * GD) / NSLOT == g) dma_slot(SL, wb);
             });
-            if constexpr (g == 0) tile_next();
-            if constexpr (g == (GA0 >= 6 ? 2 : 0)) tile_bases();
-            if constexpr (g == (GA0 >= 6 ? 4 : 0)) tile_mask();
+            if constexpr (g == 0) tile_next_w();
+            if constexpr (g == (GA0 ? 1 : 0)) tile_next_h();
+            if constexpr (g == (GA0 ? 2 : 0)) tile_next_d();
+            if constexpr (g == (GA0 ? 3 : 0)) tile_base_x0();
+            if constexpr (g == (GA0 ? 4 : 0)) tile_base_x1();
+            if constexpr (g == (GA0 ? 5 : 0)) tile_base_dy0();
+            if constexpr (g == (GA0 ? 6 : 0)) tile_base_dy1();
+            if constexpr (g == (GA0 ? 8 : 0)) tile_mask0();
+            if constexpr (g == (GA0 ? 9 : 0)) tile_mask1();
             static_for<NSLOT>([&](auto SL) {
                 if constexpr (GA0 + (decltype(SL)::value * (G - GA0)) / NSLOT == g) addr_slot(SL);
             });
@@ -602,8 +613,12 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
         using I1_ = std::integral_constant<int, 1>;
         if (tile0 < tile1) {
             tile_first(tile0);
-            tile_bases();
-            tile_mask();
+            tile_base_x0();
+            tile_base_x1();
+            tile_base_dy0();
+            tile_base_dy1();
+            tile_mask0();
+            tile_mask1();
             static_for<NSLOT>([&](auto SL) { addr_slot(SL); });
             filler(I0_{}, I1_{}, 0);                        // all DMAs of the first tile, then the addresses of the second
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -621,80 +636,131 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
         int xb[2];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) xb[tt] = xrow_of(0, tt);          // j = 0: the lane's part (+ the wave's k-step base if !TAPSPLIT)
-        for (int tl = tile0; tl < tile1; ++tl) {
-            const int rdb = ((tl - tile0) & 1) * BUF, wrb = BUF - rdb;
-            if constexpr (IS_BF16) {
-                // lane bases of the transposing reads of this buffer: halo (per tap and half), dY (per cout half)
-                int vt[TPW][2], ab[MT];
+        if constexpr (IS_BF16) {
+            // Fragments of k-step j + 1 are read from LDS while the 14 MFMAs of k-step j issue (two register sets): with one wave
+            // per SIMD nothing else covers the ~100+ cycles of a transposing read.  Read r of a k-step: the dY halves first (every
+            // MFMA of the k-step needs them), then the taps in the order the MFMAs consume them.  The barrier that publishes tile
+            // t + 1 sits in the MIDDLE of the last k-step (its operands left LDS a k-step ago, so nobody still reads this buffer;
+            // the DMAs were issued in the first 9 k-steps) and the first fragments of tile t + 1 are read behind the remaining
+            // MFMAs - the tile seam costs no exposed LDS latency.
+            constexpr int NRD = 2 * (MT + TPW), NMM = TPW * MT, G = NKS * NMM;
+            constexpr int MB = (NMM - 1) / 2;            // MFMA of the last k-step that the barrier follows
+            s16x4_t fa[2][MT][2], fb[2][TPW][2];
+            int vt[TPW][2], ab[MT];                      // lane bases of the transposing reads: halo (per tap and half), dY (per cout half)
+            auto set_bases = [&](int buf) {
 #pragma unroll
                 for (int ti = 0; ti < TPW; ++ti)
 #pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) vt[ti][tt] = xb[tt] + (tapoff[ti] + rdb);
+                    for (int tt = 0; tt < (GEO == 1 ? 1 : 2); ++tt) vt[ti][tt] = xb[tt] + (tapoff[ti] + buf);
 #pragma unroll
-                for (int mi = 0; mi < MT; ++mi) ab[mi] = arow[mi] + rdb + XBUF;
-                // Fragments of k-step j + 1 are read from LDS while the 14 MFMAs of k-step j issue (two register sets): with one
-                // wave per SIMD nothing else covers the ~100+ cycles of a transposing read.  Read r of a k-step: the dY halves first
-                // (every MFMA of the k-step needs them), then the taps in the order the MFMAs consume them.
-                constexpr int NRD = 2 * (MT + TPW), NMM = TPW * MT;
-                s16x4_t fa[2][MT][2], fb[2][TPW][2];
-                auto rd_one = [&](auto J, auto R) {
-                    constexpr int j = decltype(J)::value, r = decltype(R)::value, s_ = j & 1, h = r & 1;
-                    if constexpr (r < 2 * MT) {
-                        fa[s_][r >> 1][h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4_t*)(smem + (ab[r >> 1] + (j * 16 + 4 * h) * DYP)));
+                for (int mi = 0; mi < MT; ++mi) ab[mi] = arow[mi] + buf + XBUF;
+            };
+            auto rd_one = [&](auto J, auto R) {
+                constexpr int j = decltype(J)::value, r = decltype(R)::value, s_ = j & 1, h = r & 1;
+                if constexpr (r < 2 * MT) {
+                    fa[s_][r >> 1][h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4_t*)(smem + (ab[r >> 1] + (j * 16 + 4 * h) * DYP)));
+                } else {
+                    constexpr int ti = (r - 2 * MT) >> 1;
+                    if constexpr (GEO == 1) {
+                        // position bits 4, 5 (ph) -> 20, 40 halo rows; bits 6, 7 (pd) -> 100, 200; bit 2 (pw, the second half) -> 4
+                        constexpr int cj = (((j & 1) ? 20 : 0) + ((j & 2) ? 40 : 0) + ((j & 4) ? 100 : 0) + ((j & 8) ? 200 : 0) + 4 * h) * XP;
+                        fb[s_][ti][h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(smem + vt[ti][0] + cj));
                     } else {
-                        constexpr int ti = (r - 2 * MT) >> 1;
                         const int sj = ((j & 1) ? kc[0] : 0) + ((j & 2) ? kc[1] : 0) + ((j & 4) ? kc[2] : 0) + ((j & 8) ? kc[3] : 0);   // scalar
                         fb[s_][ti][h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(smem + (vt[ti][h] + sj)));
                     }
-                };
-                auto frag = [&](const s16x4_t (&f)[2]) {
-                    uint4 u;
-                    u.x = (uint32_t)(uint16_t)f[0][0] | ((uint32_t)(uint16_t)f[0][1] << 16);
-                    u.y = (uint32_t)(uint16_t)f[0][2] | ((uint32_t)(uint16_t)f[0][3] << 16);
-                    u.z = (uint32_t)(uint16_t)f[1][0] | ((uint32_t)(uint16_t)f[1][1] << 16);
-                    u.w = (uint32_t)(uint16_t)f[1][2] | ((uint32_t)(uint16_t)f[1][3] << 16);
-                    return u;
-                };
-                static_for<NRD>([&](auto R) { rd_one(I0_{}, R); });
-                static_for<NKS>([&](auto J) {
-                    constexpr int j = decltype(J)::value;
-                    static_for<NMM>([&](auto M) {
-                        constexpr int m = decltype(M)::value, ti = m / MT, mi = m % MT;
-                        mma_step<T>(frag(fa[j & 1][mi]), frag(fb[j & 1][ti]), acc[ti][mi]);
-                        if constexpr (j + 1 < NKS) {
-                            static_for<NRD>([&](auto R) {
-                                if constexpr ((decltype(R)::value * NMM) / NRD == m) rd_one(std::integral_constant<int, j + 1>{}, R);
-                            });
-                        }
-                        filler(std::integral_constant<int, j * NMM + m>{}, std::integral_constant<int, NKS * NMM>{}, wrb);
-                        __builtin_amdgcn_sched_barrier(0);
-                    });
+                }
+            };
+            auto frag = [&](const s16x4_t (&f)[2]) {
+                uint4 u;
+                u.x = (uint32_t)(uint16_t)f[0][0] | ((uint32_t)(uint16_t)f[0][1] << 16);
+                u.y = (uint32_t)(uint16_t)f[0][2] | ((uint32_t)(uint16_t)f[0][3] << 16);
+                u.z = (uint32_t)(uint16_t)f[1][0] | ((uint32_t)(uint16_t)f[1][1] << 16);
+                u.w = (uint32_t)(uint16_t)f[1][2] | ((uint32_t)(uint16_t)f[1][3] << 16);
+                return u;
+            };
+            // bias gradient = channel sums of dY: this thread's 8 pieces of the tile being reduced (LDS slot tid * 16 of each 4 KB dY
+            // slot holds channel piece dsw, written by this wave's own DMA); only the workgroups of input-channel chunk 0 run the
+            // copy of the loop that carries it - one piece per two k-steps, read in one and summed behind MFMAs of the next
+            uint4 ub[2];
+            auto bias_filler = [&](auto GI, int rdb) {
+                constexpr int g = decltype(GI)::value;
+                static_for<8>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    // piece i owns MFMAs [i G / 8, (i + 1) G / 8): read at a quarter of them, summed in two halves at 0.6 and 0.85
+                    constexpr int gr = (i * G + G / 4) / 8, ga = (i * G + (G * 6) / 10) / 8, ga2 = (i * G + (G * 85) / 100) / 8;
+                    if constexpr (g == gr) ub[i & 1] = *reinterpret_cast<const uint4*>(smem + rdb + XBUF + tid * 16 + i * 4096);
+                    if constexpr (g == ga) {
+                        const uint4 u = ub[i & 1];
+                        bsum[0] += __uint_as_float(u.x << 16); bsum[1] += __uint_as_float(u.x & 0xFFFF0000u);
+                        bsum[2] += __uint_as_float(u.y << 16); bsum[3] += __uint_as_float(u.y & 0xFFFF0000u);
+                    }
+                    if constexpr (g == ga2) {
+                        const uint4 u = ub[i & 1];
+                        bsum[4] += __uint_as_float(u.z << 16); bsum[5] += __uint_as_float(u.z & 0xFFFF0000u);
+                        bsum[6] += __uint_as_float(u.w << 16); bsum[7] += __uint_as_float(u.w & 0xFFFF0000u);
+                    }
                 });
-            } else {
+            };
+            auto tiles = [&](auto BIAS) {
+                if (tile0 < tile1) {
+                    set_bases(0);
+                    static_for<NRD>([&](auto R) { rd_one(I0_{}, R); });
+                }
+                for (int tl = tile0; tl < tile1; ++tl) {
+                    const int rdb = ((tl - tile0) & 1) * BUF, wrb = BUF - rdb;
+                    static_for<NKS>([&](auto J) {
+                        constexpr int j = decltype(J)::value;
+                        static_for<NMM>([&](auto M) {
+                            constexpr int m = decltype(M)::value, ti = m / MT, mi = m % MT;
+                            mma_step<T>(frag(fa[j & 1][mi]), frag(fb[j & 1][ti]), acc[ti][mi]);
+                            __builtin_amdgcn_sched_barrier(0);           // (the MFMA first: its fillers issue under it, not in front of it)
+                            if constexpr (j + 1 < NKS) {
+                                static_for<NRD>([&](auto R) {
+                                    if constexpr ((decltype(R)::value * NMM) / NRD == m) rd_one(std::integral_constant<int, j + 1>{}, R);
+                                });
+                            } else {
+                                if constexpr (m == MB) {
+                                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile tl + 1 have landed ...
+                                    __syncthreads();                                   // ... everyone's have; and nobody reads buffer rdb any more
+                                    set_bases(wrb);
+                                }
+                                if constexpr (m > MB) {                                // k-step 0 of tile tl + 1 (register set 0; this k-step runs on set 1)
+                                    static_for<NRD>([&](auto R) {
+                                        if constexpr (MB + 1 + (decltype(R)::value * (NMM - MB - 1)) / NRD == m) rd_one(I0_{}, R);
+                                    });
+                                }
+                            }
+                            filler(std::integral_constant<int, j * NMM + m>{}, std::integral_constant<int, G>{}, wrb);
+                            if constexpr (decltype(BIAS)::value) bias_filler(std::integral_constant<int, j * NMM + m>{}, rdb);
+                            __builtin_amdgcn_sched_barrier(0);
+                        });
+                    });
+                }
+            };
+            static_assert((NKS & 1) == 0, "the last k-step must run on register set 1");
+            if (do_bias) tiles(std::true_type{});
+            else tiles(std::false_type{});
+        } else {
+            for (int tl = tile0; tl < tile1; ++tl) {
+                const int rdb = ((tl - tile0) & 1) * BUF, wrb = BUF - rdb;
                 // exact f32: the same double-buffered DMA staging, the f32 reduction (two taps / chunks per MFMA) on buffer rdb
                 constexpr int NIT2_ = TAPSPLIT ? 64 : 16;
                 f32_tile(smem + rdb, smem + rdb + XBUF, [&](auto IT) { filler(IT, std::integral_constant<int, NIT2_>{}, wrb); });
-            }
-            if (do_bias) {
-                // bias gradient = channel sums of dY: this thread's 8 pieces of the tile just reduced (LDS slot tid * 16 of
-                // each 4 KB dY slot holds channel piece dsw); only the workgroups of input-channel chunk 0 (uniform branch)
+                if (do_bias) {
+                    // bias gradient = channel sums of dY: this thread's 8 pieces of the tile just reduced (LDS slot tid * 16 of
+                    // each 4 KB dY slot holds channel piece dsw); only the workgroups of input-channel chunk 0 (uniform branch)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const uint4 u = *reinterpret_cast<const uint4*>(smem + rdb + XBUF + tid * 16 + i * 4096);
-                    if constexpr (IS_BF16) {
-                        bsum[0] += __uint_as_float(u.x << 16); bsum[1] += __uint_as_float(u.x & 0xFFFF0000u);
-                        bsum[2] += __uint_as_float(u.y << 16); bsum[3] += __uint_as_float(u.y & 0xFFFF0000u);
-                        bsum[4] += __uint_as_float(u.z << 16); bsum[5] += __uint_as_float(u.z & 0xFFFF0000u);
-                        bsum[6] += __uint_as_float(u.w << 16); bsum[7] += __uint_as_float(u.w & 0xFFFF0000u);
-                    } else {
+                    for (int i = 0; i < 8; ++i) {
+                        const uint4 u = *reinterpret_cast<const uint4*>(smem + rdb + XBUF + tid * 16 + i * 4096);
                         bsum[0] += __uint_as_float(u.x); bsum[1] += __uint_as_float(u.y);
                         bsum[2] += __uint_as_float(u.z); bsum[3] += __uint_as_float(u.w);
                     }
                 }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile tl + 1 have landed ...
+                __syncthreads();                                   // ... everyone's have; and buffer rdb is free
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile tl + 1 have landed ...
-            __syncthreads();                                   // ... everyone's have; and buffer rdb is free
         }
     } else {
         constexpr bool PF = (MAXP <= 10);      // big-halo (strided) variant: no cross-tile prefetch, it would spill
@@ -971,9 +1037,12 @@ thread_local VariantOut* g_wvariant = nullptr;      // see rho_conv_variant (con
 
 template <typename T, int KD, int KH, int KW>
 int launch_wgrad(const WgradK& k, int maxp, dim3 grid, size_t lds, hipStream_t st) {
+    // the compile-time tile geometry of k_wgrad<..., GEO = 1>
+    const bool geo488 = k.TD == 4 && k.TH == 8 && k.TW == 8 && k.IH == 10 && k.IW == 10 && k.sh == 1 && k.sw == 1;
     if (g_wvariant != nullptr) {
-        snprintf(g_wvariant->buf, (size_t)g_wvariant->cap, "k_wgrad<%s,%d,%d,%d,MAXP=%d,PRE=%d>", sizeof(T) == 2 ? "bf16" : "f32", KD, KH,
-                 KW, maxp <= 10 ? 10 : 28, k.pre_a != nullptr ? 1 : 0);
+        snprintf(g_wvariant->buf, (size_t)g_wvariant->cap, "k_wgrad<%s,%d,%d,%d,MAXP=%d,PRE=%d%s>", sizeof(T) == 2 ? "bf16" : "f32", KD, KH,
+                 KW, maxp <= 10 ? 10 : 28, k.pre_a != nullptr ? 1 : 0,
+                 (geo488 && sizeof(T) == 2 && KD == 3 && KH == 3 && KW == 3 && maxp <= 10 && k.pre_a == nullptr) ? ",GEO=1" : "");
         return 0;
     }
     auto go = [&](auto fn) -> int {
@@ -989,6 +1058,9 @@ int launch_wgrad(const WgradK& k, int maxp, dim3 grid, size_t lds, hipStream_t s
     if constexpr (KH == 2 || KW == 2) {      // sub-pixel phases: stride 1, small halo, no prologue (checked by the caller)
         if (maxp > 10 || pre) return RHO_E_SHAPE;
         return go(k_wgrad<T, KD, KH, KW, 10, false>);
+    }
+    if constexpr (sizeof(T) == 2 && KD == 3 && KH == 3 && KW == 3) {
+        if (geo488 && !pre && maxp <= 10) return go(k_wgrad<T, KD, KH, KW, 10, false, 1>);
     }
     if (maxp <= 10) return pre ? go(k_wgrad<T, KD, KH, KW, 10, true>) : go(k_wgrad<T, KD, KH, KW, 10, false>);
     return pre ? go(k_wgrad<T, KD, KH, KW, 28, true>) : go(k_wgrad<T, KD, KH, KW, 28, false>);

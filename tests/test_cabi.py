@@ -84,3 +84,55 @@ def test_conv_desc_struct_layout():
         fields.extend(n.strip().lstrip("*") for n in names[1:])
     assert [f[0] for f in ConvDesc._fields_] == fields
     assert ctypes.sizeof(ConvDesc) == 10 * 8 + 26 * 4 + 8 + 8 + 4 * 4 + (2 * 8 + 2 * 4 + 2 * 8) + 2 * 8 + (4 * 8 + 2 * 4)
+
+
+def _gfx950_code_objects(path):
+    """(offset, size) of every gfx950 code object in the library's clang offload bundles."""
+    import struct
+    blob = open(path, "rb").read()
+    out = []
+    for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", blob):
+        p = m.start()
+        (n,) = struct.unpack_from("<Q", blob, p + 24)
+        o = p + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", blob, o)
+            o += 24
+            triple = blob[o:o + tl].decode()
+            o += tl
+            if "gfx950" in triple and size:
+                out.append(blob[p + off:p + off + size])
+    return out
+
+
+def test_m0_is_only_written_by_the_lds_dma_statements(tmp_path):
+    """k_wgrad's LDS-DMA statements leave M0 (the DMA's LDS base) as they set it instead of saving and restoring it around
+    every DMA; that is only sound while nothing the compiler emits reads or writes M0.  Disassemble the built library:
+    every instruction that mentions m0 must be a scalar move to / from m0, and every move TO m0 must be followed, within
+    two instructions, by the global_load_lds it serves."""
+    import shutil
+    import subprocess
+    from rho_diffusion_amd import hip
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump) or not os.path.exists(hip.LIB_PATH):
+        pytest.skip("no llvm-objdump / library")
+    objs = _gfx950_code_objects(hip.LIB_PATH)
+    assert objs, "no gfx950 code object in the library"
+    n_dma = 0
+    for i, blob in enumerate(objs):
+        f = tmp_path / f"co{i}.o"
+        f.write_bytes(blob)
+        text = subprocess.run([objdump, "-d", "--no-show-raw-insn", str(f)], capture_output=True, text=True, check=True).stdout
+        if "m0" not in text:
+            continue
+        lines = [l.strip() for l in text.split("\n")]
+        for k, l in enumerate(lines):
+            if not re.search(r"\bm0\b", l):
+                continue
+            assert re.match(r"s_mov_b32 (m0, s\d+|s\d+, m0)\b", l), f"unexpected use of m0: {l}"
+            if l.startswith("s_mov_b32 m0"):
+                nxt = [x for x in lines[k + 1:k + 4] if x]
+                assert any(x.startswith("global_load_lds") for x in nxt[:2]), f"m0 written without a DMA behind it: {l} / {nxt}"
+                n_dma += 1
+    assert n_dma > 0
+    shutil.rmtree(tmp_path, ignore_errors=True)
