@@ -37,7 +37,7 @@ extern "C" {
 /* ABI version: bumped on ANY signature / struct-layout change (2: table_len in rho_q_sample(_coef), fmt in rho_gn_bwd_finalize,
  * rho_conv_desc grew; 3: round-3 additions).  A loader must compare rho_abi_version() with the header it was written against
  * before calling anything else (hip.py does; a build with all symbols but older signatures would be called with shifted arguments). */
-#define RHO_ABI_VERSION 7
+#define RHO_ABI_VERSION 8
 int rho_abi_version(void);
 /* static string: target arch + build flags */
 const char* rho_build_info(void);
@@ -259,6 +259,19 @@ typedef struct rho_conv_desc {
     const void* sk_w;
     const float* sk_bias;
     int32_t sk_c1, sk_c2;
+    /* --- GroupNorm BACKWARD apply pass fused into a data-gradient launch: with gna_g set the launch writes
+     *     out = conv(x) [+ res / res2]  +  cA * (g * act'(a * x0 + b)) + cQ * x0 + cP
+     * per channel of its (one or two) channels-last outputs - the second operand is what rho_gn_bwd_apply computes from g = the
+     * gradient of act(GroupNorm(x0)), channels-last [positions][cout] over BOTH output regions, and x0 = the forward input of that
+     * norm (gnb_x1 / gnb_x2 / gnb_c1, gnb_a / gnb_b = its folded affine, gnb_silu its activation 0 / 1).  cA [N][cout],
+     * cP / cQ [N][32] are rho_gn_bwd_finalize's coefficients.  Used for the ResBlock whose input reaches its output through a
+     * 1x1x1 skip convolution (unet_v2.py:245-256): dX = skip^T(dY) + GroupNorm-backward(in-conv path) in ONE launch instead of a
+     * data-gradient launch plus an apply pass that re-reads and re-writes dX.  Needs one-sample tiles (rho_conv_stats_tiles > 0),
+     * no `stats`, a second region (if any) that is channels-last (y2_cl) and a multiple of 8 (bf16) / 4 (f32) channels wide. */
+    const void* gna_g;
+    const float* gna_cA;
+    const float* gna_cP;
+    const float* gna_cQ;
 } rho_conv_desc;
 
 /* n-D convolution, zero padding k/2, as an LDS-halo-staged implicit GEMM on MFMA.

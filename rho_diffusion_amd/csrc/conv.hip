@@ -87,6 +87,11 @@ struct ConvK {
     const char* sk_w;
     const float* sk_bias;
     int sk_c1, sk_c2;
+    // GroupNorm backward APPLY fused into the epilogue (rho_conv_desc.gna_*): out += cA * (g * act'(a x0 + b)) + cQ * x0 + cP
+    const char* gna_g;
+    const float* gna_cA;
+    const float* gna_cP;
+    const float* gna_cQ;
 };
 
 // floor(a / d) for 0 <= a < 2^20 with inv = 1.0f / d: (a + 0.5) * inv is at least 0.5 / d away from an integer, the
@@ -128,7 +133,9 @@ __device__ __forceinline__ int tile_position16(int m16, int i, int TW, int pair_
     return unit_position(2 * (m16 >> 1) + m16_hb(i), 2 * m16_k8(i) + (m16 & 1), TW, pair_lg);
 }
 
-template <typename T, int KD, int KH, int KW, int BM, int MAXP, int NW, bool M16 = false, bool FSK = false>
+// GNA: the 1x1x1 instantiations whose epilogue carries the GroupNorm backward apply (rho_conv_desc.gna_*; no residual operand there:
+// its 32 registers are what the extra operand takes)
+template <typename T, int KD, int KH, int KW, int BM, int MAXP, int NW, bool M16 = false, bool FSK = false, bool GNA = false>
 // (second launch bound = waves per SIMD the register allocation must allow: 2 for the 8-wave variants and for the 4-wave 1x1x1
 //  variant, which without it took 241 VGPRs + 64 AGPRs = one workgroup per CU and left its HBM-bound layers at 3.3 TB/s)
 __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 10)) ? 2 : 1) void k_conv(const ConvK p) {
@@ -913,8 +920,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
         }
         return;
     }
-    const bool cl_region = (co0 < q.split);
+    // (round 4: the second channels-last region of a launch - the gradient of the second source of a concatenated input - takes the
+    //  same transposed path when its width is whole 16-byte pieces: the fused GroupNorm-backward apply needs both regions here)
+    const bool reg2 = q.y2_cl && co0 >= q.split && ((q.cout - q.split) % PE == 0);
+    const bool cl_region = (co0 < q.split) || reg2;
     if (cl_region) {
+        const int rw = reg2 ? q.cout - q.split : q.split;          // row width of this region's tensor
+        const int rc0 = reg2 ? co0 - q.split : co0;                // first channel of this tile inside it
+        char* const ry = reg2 ? q.y2 : q.y;
+        const char* const rrp = reg2 ? q.res2 : q.res;
+        const float* const radd = reg2 ? nullptr : q.res_add;
         // Channels-last output (every block of this launch region: BM divides split).  The accumulator layout gives a
         // lane 4 channels of one position, i.e. 8-byte stores (and residual loads) scattered over 32 rows per
         // instruction.  Transpose through LDS instead (the halo / weight space is free now): fp32 rows of BM channels,
@@ -952,23 +967,39 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
             constexpr int NIT = 256 * PPR / NTHR;
             static_assert(256 * PPR % NTHR == 0, "whole items per thread");
             int eoff[NIT];                                   // output position (the host guarantees < 2^31 positions), -1 = outside
-            uint4 rres[NIT];
+            uint4 rres[GNA ? 1 : NIT];
             uint4 gx[NIT];                                  // gnb: this thread's piece of the forward input at its output positions
             float bia[PE];                                  // bias (+ the per-sample additive term, 3-D: one sample per tile)
             float gna[PE], gnb[PE];                         // gnb: folded affine of the forward prologue, this thread's channels
             const bool gnb_on = q.gnb_x1 != nullptr;
+            // gna: the GroupNorm backward apply of this thread's channels rides in the store loop (rho_conv_desc.gna_*)
+            const bool gna_on = GNA && q.gna_g != nullptr;
+            uint4 gg[GNA ? NIT : 1];
+            float gca[GNA ? PE : 1], gcp[GNA ? PE : 1], gcq[GNA ? PE : 1];
             {
                 const int piece = tid % PPR;
                 const int gco = co0 + piece * PE;           // the piece lies in one concat source (widths are multiples of 32)
                 const bool g_first = gco < q.gnb_c1;
                 const char* const gsrc = g_first ? q.gnb_x1 : q.gnb_x2;
-                const int gcs = g_first ? q.gnb_c1 : q.split - q.gnb_c1, gch = g_first ? gco : gco - q.gnb_c1;
+                // (statistics: one tensor of `split` channels; apply: the concat of both regions, cout channels)
+                const int gC = gna_on ? q.cout : q.split;
+                const int gcs = g_first ? q.gnb_c1 : gC - q.gnb_c1, gch = g_first ? gco : gco - q.gnb_c1;
                 if (gnb_on) {
                     const int nsg = n + bt / q.tps;         // the tile's sample (statistics are only fused for one-sample tiles)
 #pragma unroll
                     for (int e = 0; e < PE; ++e) {
-                        gna[e] = q.gnb_a[(size_t)nsg * q.split + gco + e];
-                        gnb[e] = q.gnb_b[(size_t)nsg * q.split + gco + e];
+                        gna[e] = q.gnb_a[(size_t)nsg * gC + gco + e];
+                        gnb[e] = q.gnb_b[(size_t)nsg * gC + gco + e];
+                    }
+                    if constexpr (GNA) {
+                        const int cpg = gC / 32;
+#pragma unroll
+                        for (int e = 0; e < PE; ++e) {
+                            const int ce = (gco + e < gC) ? gco + e : gC - 1;        // (padding pieces of the last tile: never stored)
+                            gca[e] = q.gna_cA[(size_t)nsg * gC + ce];
+                            gcp[e] = q.gna_cP[(size_t)nsg * 32 + ce / cpg];
+                            gcq[e] = q.gna_cQ[(size_t)nsg * 32 + ce / cpg];
+                        }
                     }
                 }
 #pragma unroll
@@ -982,8 +1013,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                         }
                     }
                     if constexpr (KD == 3) {
-                        if (q.res_add != nullptr) {
-                            const float4 e = *reinterpret_cast<const float4*>(q.res_add + (long long)n * q.res_add_stride + co0 + piece * PE + q4 * 4);
+                        if (radd != nullptr) {
+                            const float4 e = *reinterpret_cast<const float4*>(radd + (long long)n * q.res_add_stride + co0 + piece * PE + q4 * 4);
                             bia[q4 * 4 + 0] += e.x; bia[q4 * 4 + 1] += e.y; bia[q4 * 4 + 2] += e.z; bia[q4 * 4 + 3] += e.w;
                         }
                     }
@@ -997,14 +1028,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                     const int ph = (pp >> q.lgTW) & (q.TH - 1);
                     const int pd = pp >> (q.lgTW + q.lgTH);
                     const int od = od0 + pd, oh = oh0 + ph, ow = ow0 + pw;
-                    const bool ok = od < q.Do && oh < q.Ho && ow < q.Wo;
+                    // (the last tile of the second region may reach past its tensor)
+                    const bool ok = od < q.Do && oh < q.Ho && ow < q.Wo && (rc0 + piece * PE + PE <= rw);
                     const int L = ((n * q.Do + od) * q.Ho_out + (oh * q.oy_mul + q.oy_add)) * q.Wo_out + (ow * q.ox_mul + q.ox_add);
                     eoff[k] = ok ? L : -1;
-                    rres[k] = make_uint4(0u, 0u, 0u, 0u);
-                    if (ok && q.res != nullptr)     // (32 x 32 -> 64-bit multiply: one v_mad_u64_u32 instead of a 64 x 64 sequence)
-                        rres[k] = *reinterpret_cast<const uint4*>(q.res + ((size_t)(unsigned)L * (unsigned)q.split + (unsigned)(co0 + piece * PE)) * sizeof(T));
+                    if constexpr (!GNA) {
+                        rres[k] = make_uint4(0u, 0u, 0u, 0u);
+                        if (ok && rrp != nullptr)   // (32 x 32 -> 64-bit multiply: one v_mad_u64_u32 instead of a 64 x 64 sequence)
+                            rres[k] = *reinterpret_cast<const uint4*>(rrp + ((size_t)(unsigned)L * (unsigned)rw + (unsigned)(rc0 + piece * PE)) * sizeof(T));
+                    }
                     gx[k] = make_uint4(0u, 0u, 0u, 0u);
                     if (ok && gnb_on) gx[k] = *reinterpret_cast<const uint4*>(gsrc + ((size_t)(unsigned)L * (unsigned)gcs + (unsigned)gch) * sizeof(T));
+                    if constexpr (GNA) {
+                        gg[k] = make_uint4(0u, 0u, 0u, 0u);
+                        if (ok) gg[k] = *reinterpret_cast<const uint4*>(q.gna_g + ((size_t)(unsigned)L * (unsigned)gC + (unsigned)gco) * sizeof(T));
+                    }
                 }
             }
             __syncthreads();
@@ -1021,18 +1059,43 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                     v[q4 * 4 + 0] = a4.x + bia[q4 * 4 + 0]; v[q4 * 4 + 1] = a4.y + bia[q4 * 4 + 1];
                     v[q4 * 4 + 2] = a4.z + bia[q4 * 4 + 2]; v[q4 * 4 + 3] = a4.w + bia[q4 * 4 + 3];
                 }
-                if (KD != 3 && q.res_add != nullptr) {
+                if (KD != 3 && radd != nullptr) {
                     const long long ns = (long long)L / q.S_out;
 #pragma unroll
                     for (int q4 = 0; q4 < PE / 4; ++q4) {
-                        const float4 e = *reinterpret_cast<const float4*>(q.res_add + ns * q.res_add_stride + co + q4 * 4);
+                        const float4 e = *reinterpret_cast<const float4*>(radd + ns * q.res_add_stride + co + q4 * 4);
                         v[q4 * 4 + 0] += e.x; v[q4 * 4 + 1] += e.y; v[q4 * 4 + 2] += e.z; v[q4 * 4 + 3] += e.w;
                     }
                 }
-                const size_t eo = (size_t)(unsigned)L * (unsigned)q.split + (unsigned)co;
+                const size_t eo = (size_t)(unsigned)L * (unsigned)rw + (unsigned)(rc0 + piece * PE);
+                if constexpr (GNA) {
+                    // + cA * (g * act'(a x0 + b)) + cQ * x0 + cP: rho_gn_bwd_apply's term, from the operands that pass read
+                    float xv[PE], gv[PE];
+                    if constexpr (sizeof(T) == 2) {
+                        const uint4 a_ = gx[k], b_ = gg[k];
+                        xv[0] = __uint_as_float(a_.x << 16); xv[1] = __uint_as_float(a_.x & 0xFFFF0000u);
+                        xv[2] = __uint_as_float(a_.y << 16); xv[3] = __uint_as_float(a_.y & 0xFFFF0000u);
+                        xv[4] = __uint_as_float(a_.z << 16); xv[5] = __uint_as_float(a_.z & 0xFFFF0000u);
+                        xv[6] = __uint_as_float(a_.w << 16); xv[7] = __uint_as_float(a_.w & 0xFFFF0000u);
+                        gv[0] = __uint_as_float(b_.x << 16); gv[1] = __uint_as_float(b_.x & 0xFFFF0000u);
+                        gv[2] = __uint_as_float(b_.y << 16); gv[3] = __uint_as_float(b_.y & 0xFFFF0000u);
+                        gv[4] = __uint_as_float(b_.z << 16); gv[5] = __uint_as_float(b_.z & 0xFFFF0000u);
+                        gv[6] = __uint_as_float(b_.w << 16); gv[7] = __uint_as_float(b_.w & 0xFFFF0000u);
+                    } else {
+                        const uint4 a_ = gx[k], b_ = gg[k];
+                        xv[0] = __uint_as_float(a_.x); xv[1] = __uint_as_float(a_.y); xv[2] = __uint_as_float(a_.z); xv[3] = __uint_as_float(a_.w);
+                        gv[0] = __uint_as_float(b_.x); gv[1] = __uint_as_float(b_.y); gv[2] = __uint_as_float(b_.z); gv[3] = __uint_as_float(b_.w);
+                    }
+#pragma unroll
+                    for (int e = 0; e < PE; ++e) {
+                        float gq = gv[e];
+                        if (q.gnb_silu) gq *= dsilu_f(fmaf(gna[e], xv[e], gnb[e]));
+                        v[e] += fmaf(gca[e], gq, fmaf(gcq[e], xv[e], gcp[e]));
+                    }
+                }
                 if constexpr (sizeof(T) == 2) {
-                    if (q.res != nullptr) {
-                        const uint4 r = rres[k];
+                    if (!GNA && rrp != nullptr) {
+                        const uint4 r = rres[GNA ? 0 : k];
                         v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xFFFF0000u);
                         v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xFFFF0000u);
                         v[4] += __uint_as_float(r.z << 16); v[5] += __uint_as_float(r.z & 0xFFFF0000u);
@@ -1042,7 +1105,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                     {   // streaming store: the 1 GB outputs do not fit the caches, keep L2 for the halo re-reads (whole step -0.5 %)
                         typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
                         const u32x4_nt ov = {o.x, o.y, o.z, o.w};
-                        __builtin_nontemporal_store(ov, reinterpret_cast<u32x4_nt*>(q.y + eo * 2));
+                        __builtin_nontemporal_store(ov, reinterpret_cast<u32x4_nt*>(ry + eo * 2));
                     }
                     if (q.stats != nullptr) {             // statistics of the values as stored (what a reader would see)
                         v[0] = __uint_as_float(o.x << 16); v[1] = __uint_as_float(o.x & 0xFFFF0000u);
@@ -1051,14 +1114,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (KD * KH * KW == 1 && MAXP <= 
                         v[6] = __uint_as_float(o.w << 16); v[7] = __uint_as_float(o.w & 0xFFFF0000u);
                     }
                 } else {
-                    if (q.res != nullptr) {
-                        const uint4 r = rres[k];
+                    if (!GNA && rrp != nullptr) {
+                        const uint4 r = rres[GNA ? 0 : k];
                         v[0] += __uint_as_float(r.x); v[1] += __uint_as_float(r.y); v[2] += __uint_as_float(r.z); v[3] += __uint_as_float(r.w);
                     }
-                    *reinterpret_cast<float4*>(q.y + eo * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(ry + eo * 4) = make_float4(v[0], v[1], v[2], v[3]);
                 }
                 if (q.stats != nullptr) {
-                    if (gnb_on) {
+                    if (gnb_on && !gna_on) {
                         // dgrad of a conv behind GroupNorm (+SiLU): v = d act(a x + b) as stored; the norm's backward needs the
                         // per-channel sums of dz = v * act'(a x + b) and of dz * x (rho_gn_bwd_finalize, fmt 1)
                         float xv[PE];
@@ -1270,14 +1333,14 @@ struct VariantOut {
 };
 thread_local VariantOut* g_variant = nullptr;
 
-template <typename T, int KD, int KH, int KW, int BM, int MAXP, int NW, bool M16 = false, bool FSK = false>
+template <typename T, int KD, int KH, int KW, int BM, int MAXP, int NW, bool M16 = false, bool FSK = false, bool GNA = false>
 int launch_one(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
     if (g_variant != nullptr) {
-        snprintf(g_variant->buf, (size_t)g_variant->cap, "k_conv<%s,%d,%d,%d,BM=%d,MAXP=%d,NW=%d,M16=%d>%s", sizeof(T) == 2 ? "bf16" : "f32",
-                 KD, KH, KW, BM, MAXP, NW, (int)M16, FSK ? "+skip" : "");
+        snprintf(g_variant->buf, (size_t)g_variant->cap, "k_conv<%s,%d,%d,%d,BM=%d,MAXP=%d,NW=%d,M16=%d>%s%s", sizeof(T) == 2 ? "bf16" : "f32",
+                 KD, KH, KW, BM, MAXP, NW, (int)M16, FSK ? "+skip" : "", GNA ? "+gn_apply" : "");
         return 0;
     }
-    auto fn = k_conv<T, KD, KH, KW, BM, MAXP, NW, M16, FSK>;
+    auto fn = k_conv<T, KD, KH, KW, BM, MAXP, NW, M16, FSK, GNA>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -1307,6 +1370,15 @@ int launch_bm(const ConvK& k, int BM, int np, dim3 grid, size_t lds, bool m16, h
         }
     }
     if (k.sk_w != nullptr) return RHO_E_ARG;               // a folded skip needs one of the two variants above
+    if (k.gna_g != nullptr) {                              // GroupNorm backward apply in the epilogue: the 1x1x1 instantiations
+        if constexpr (KD * KH * KW == 1) {
+            if (np > 640) return RHO_E_SHAPE;
+            if (BM == 128) return launch_one<T, 1, 1, 1, 128, 5, 8, false, false, true>(k, grid, lds, st);
+            if (BM == 64) return launch_one<T, 1, 1, 1, 64, 10, 4, false, false, true>(k, grid, lds, st);
+            return launch_one<T, 1, 1, 1, 32, 10, 4, false, false, true>(k, grid, lds, st);
+        }
+        return RHO_E_ARG;
+    }
     if (BM == 128) {
         if (np <= 640) return launch_one<T, KD, KH, KW, 128, 5, 8>(k, grid, lds, st);
         if constexpr (!PHASE) return launch_one<T, KD, KH, KW, 128, 14, 8>(k, grid, lds, st);
@@ -1480,11 +1552,10 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
     k.cofast = (d.coutp / BM > 1 && tiles % 8 == 0) ? 1 : 0;
     dim3 grid((unsigned)tiles, (unsigned)(d.coutp / BM), (unsigned)gridz);
     // fused output statistics: only where a tile belongs to one sample and the whole output is channels-last
-    int64_t tps = 0;
-    if (d.split == d.cout && d.split > 0) {
-        if (d.kd == 3) tps = tiles * n_phase;            // phases: the launches of one output share the buffer, each its own tile range
-        else if (taps == 1 && k.S_out % 256 == 0 && t.TW == 256) tps = k.S_out / 256;
-    }
+    int64_t tps_geo = 0;                                 // tiles per sample where every tile lies in one sample, else 0
+    if (d.kd == 3) tps_geo = tiles * n_phase;            // phases: the launches of one output share the buffer, each its own tile range
+    else if (taps == 1 && k.S_out % 256 == 0 && t.TW == 256) tps_geo = k.S_out / 256;
+    const int64_t tps = (d.split == d.cout && d.split > 0) ? tps_geo : 0;
     if (stats_tiles) { *stats_tiles = tps; return 0; }
     // k-split (rho_conv_desc.ws): merged-batch launches (2-D / 1-D kernels with taps) whose grid leaves most CUs idle
     int ksplit = 1;
@@ -1493,7 +1564,7 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
         const long long wgs = tiles * (d.coutp / BM);
         const int chunks = cin / CK;
         static const bool split_env = !(getenv("RHO_CONV_SPLITK") && atoi(getenv("RHO_CONV_SPLITK")) == 0);
-        if (split_env && d.kd == 1 && (d.split == d.cout || d.y2_cl) && !d.stats && wgs <= 128 && chunks >= 4) {
+        if (split_env && d.kd == 1 && (d.split == d.cout || d.y2_cl) && !d.stats && !d.gna_g && wgs <= 128 && chunks >= 4) {
             int want = (int)(512 / wgs);                               // about two workgroups per CU
             if (want > 16) want = 16;
             const int per = taps == 1 ? 4 : 2;                         // chunks per split at least: the set-up of a tile is paid per split
@@ -1515,7 +1586,19 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
         k.stats_off = phase_idx * (int)tiles;
     }
     k.gnb_x1 = nullptr;
-    if (d.gnb_x1) {
+    k.gna_g = nullptr;
+    if (d.gna_g) {
+        // GroupNorm backward apply in the epilogue: both output regions on the transposed path, one sample per tile
+        const int pe = d.dtype == RHO_BF16 ? 8 : 4;
+        if (taps != 1 || d.res || d.res2 || d.stats || !d.gnb_x1 || !d.gnb_a || !d.gnb_b || !d.gna_cA || !d.gna_cP || !d.gna_cQ || d.split <= 0 || d.cout % 32 ||
+            d.gnb_c1 <= 0 || d.gnb_c1 > d.cout || d.gnb_c1 % 32 || ((d.gnb_c1 < d.cout) != (d.gnb_x2 != nullptr)) || tps_geo <= 0 ||
+            (d.split < d.cout && (!d.y2_cl || (d.cout - d.split) % pe != 0)) || d.gnb_silu < 0 || d.gnb_silu > 1 || n_phase != 1)
+            return RHO_E_ARG;
+        k.gnb_x1 = (const char*)d.gnb_x1; k.gnb_x2 = (const char*)d.gnb_x2; k.gnb_a = d.gnb_a; k.gnb_b = d.gnb_b;
+        k.gnb_c1 = d.gnb_c1; k.gnb_silu = d.gnb_silu;
+        k.gna_g = (const char*)d.gna_g; k.gna_cA = d.gna_cA; k.gna_cP = d.gna_cP; k.gna_cQ = d.gna_cQ;
+        k.tps = (int)tps_geo;
+    } else if (d.gnb_x1) {
         if (!d.stats || !d.gnb_a || !d.gnb_b || d.gnb_c1 <= 0 || d.gnb_c1 > d.split || d.gnb_c1 % 32 || (d.split - d.gnb_c1) % 32 ||
             ((d.gnb_c1 < d.split) != (d.gnb_x2 != nullptr)))
             return RHO_E_ARG;
@@ -1546,7 +1629,7 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
     if (lds < lds_sk) lds = lds_sk;
     if (d.stats) { const size_t lr = (size_t)(BM == 128 ? 512 : 256) * 16 * sizeof(float); if (lds < lr) lds = lr; }
     const size_t lds_epi = (size_t)256 * (BM * 4 + 16);       // epilogue transpose staging (fp32 rows, all 256 positions at once)
-    if (d.split > 0 && lds < lds_epi) lds = lds_epi;
+    if ((d.split > 0 || d.y2_cl) && lds < lds_epi) lds = lds_epi;
     hipStream_t st = as_stream(stream);
     const bool m16_env = m16_env_on();
     const int rc = d.dtype == RHO_BF16 ? launch_taps<bf16_raw>(d, k, BM, t.NP, grid, lds, m16 && m16_env, st)

@@ -523,7 +523,8 @@ class UNetEngine:
     # environment switches a plan reads while it is built (A/B knobs): part of the plan key, so flipping one rebuilds the plan
     _PLAN_ENV = ("RHO_TRAIN_MATERIALIZE", "RHO_MATERIALIZE_MIN_COUT", "RHO_PHASE_UPSAMPLE", "RHO_PHASE_UPSAMPLE_BWD", "RHO_PHASE_MIN_WGS",
                  "RHO_FOLD_SKIP", "RHO_FOLD_SKIP_TRAIN", "RHO_S2_SPLIT", "RHO_S2_SPLIT_BWD", "RHO_FUSE_GN_BWD", "RHO_GEMM_ENDS",
-                 "RHO_DIRECT_ENDS", "RHO_CONV_SPLITK", "RHO_BATCH_PREP", "RHO_DW_ARENA", "RHO_FOLD_ADD", "RHO_FIN_BATCH_MB", "RHO_BWD_OVERLAP", "RHO_DIRECT_ENDS_TRAIN")
+                 "RHO_DIRECT_ENDS", "RHO_CONV_SPLITK", "RHO_BATCH_PREP", "RHO_DW_ARENA", "RHO_FOLD_ADD", "RHO_FIN_BATCH_MB", "RHO_BWD_OVERLAP", "RHO_DIRECT_ENDS_TRAIN",
+                 "RHO_FUSE_SKIP_DGRAD")
 
     def _plan_signature(self) -> tuple:
         """Everything besides (shape, labels, mode) that is baked into a plan when it is built: the per-ResBlock ``use_checkpoint``
@@ -574,6 +575,10 @@ class _Plan:
         # - from RHO_FUSE_GN_BWD channels up (0 = never): on the 64-channel layers the extra epilogue VALU work (one sigmoid per
         # element) costs the issue-bound narrow tiles more than the separate reduce pass it replaces
         self.fuse_gn_bwd = int(os.environ.get("RHO_FUSE_GN_BWD", "128"))
+        # backward of a ResBlock with a 1x1x1 skip convolution: the skip's data gradient and the GroupNorm backward apply of the
+        # in-conv path write the same dX - one launch (rho_conv_desc.gna_*) instead of a data-gradient launch plus an apply pass that
+        # re-reads and re-writes it (A/B switch)
+        self.fuse_skip_dgrad = os.environ.get("RHO_FUSE_SKIP_DGRAD", "1") != "0"
         m = eng.model
         dt = eng.dtype
         dtc = hip.dtype_code(dt)
@@ -1113,6 +1118,8 @@ class _Plan:
         # Any other access to G[res] flushes it as the plain rho_add_inplace first.
         fold_add = os.environ.get("RHO_FOLD_ADD", "1") != "0"
         pending_add: Dict[int, Tensor] = {}
+        skip_partner: Dict[int, int] = {}               # id(1x1x1 skip node) -> id(the block's in-conv node), see fuse_skip_dgrad
+        held_skips: Dict[int, tuple] = {}               # id(in-conv node) -> (skip node, dY, width) waiting for its GroupNorm backward
 
         def flush_add(k: int):
             src = pending_add.pop(k, None)
@@ -1340,14 +1347,27 @@ class _Plan:
             if xact is not None:
                 wput(xact)
 
-        def gn_backward(pre, pre_silu, x1, x2, dact, fused=None, drop=None):
+        def gn_backward(pre, pre_silu, x1, x2, dact, fused=None, drop=None, skip=None):
             """dact = gradient of act(GroupNorm(x) * (1 + scale) + shift): reduce / finalize / apply into the gradients of x1 (, x2),
             the norm's parameters and the FiLM rows.  ``fused`` = (tile sums, tiles per sample) when the dgrad launch that produced
-            dact already reduced dz and dz * x in its epilogue (rho_conv_desc.gnb_*): the reduce pass is skipped."""
+            dact already reduced dz and dz * x in its epilogue (rho_conv_desc.gnb_*): the reduce pass is skipped.  ``skip`` = (node,
+            dY, width) of the block's 1x1x1 skip convolution whose data gradient was held back: it runs here, with the apply pass in
+            its epilogue (rho_conv_desc.gna_*), or - where that launch does not exist - on its own in front of the apply pass."""
             c1 = x1.shape[-1]
             c2 = x2.shape[-1] if x2 is not None else 0
             norm = pre["norm"]
             Cc, N_, S_ = pre["C"], pre["N"], pre["S"]
+            skip_fused = None
+            if skip is not None:
+                sk_node, sk_dY, sk_w = skip
+                can = (drop is None and int(pre_silu) <= 1 and key(x1) not in written and key(x1) not in pending_add
+                       and (x2 is None or key(x2) not in written) and S_ % 256 == 0 and Cc % 32 == 0
+                       and (x2 is None or c2 % (8 if dt == torch.bfloat16 else 4) == 0))
+                if can:
+                    skip_fused = skip
+                else:
+                    dgrad(sk_node, sk_dY, sk_w, hold_skip=False)          # the two-pass form: data gradient first, apply accumulates
+                    pool.put(sk_dY)
             g1, acc1 = gradbuf(x1, fold_ok=True)
             add1 = pending_add.pop(key(x1), None)              # a residual's gradient waiting to join G[x1]: folded into this pass
             g2, acc2 = gradbuf(x2) if x2 is not None else (None, False)
@@ -1381,7 +1401,23 @@ class _Plan:
             a3 = (ptr(dact), ptr(x1), c1, ptr(x2), c2, dtc, N_, S_, ptr(pre["a"]), ptr(pre["b"]), int(pre_silu),
                   ptr(cA), ptr(cP), ptr(cQ), ptr(g1), ptr(g2), int(acc1), int(acc2), ptr(add1))
             nb3 = esz * N_ * S_ * (3.0 * Cc + (c1 if acc1 else 0) + (c2 if acc2 else 0) + (c1 if add1 is not None else 0))
-            if drop is not None:
+            if skip_fused is not None:
+                # dX = skip^T(dY) + [cA * (dact * act'(a x + b)) + cQ * x + cP] in the 1x1x1 data-gradient launch's epilogue
+                sk_node, sk_dY, sk_w = skip_fused
+                scw = sk_node["cw"]
+                if acc1 or acc2 or add1 is not None:
+                    raise hip.RhoHipError("internal: fused skip data gradient on a gradient that already has a writer (backward plan)")
+                d = ops.make_conv_desc(sk_dY, None, scw.wd, scw.zero_bias, kernel=scw.kernel, cout=Cc, split=c1, y=g1, y2=g2,
+                                       y2_cl=x2 is not None)
+                d.gnb_x1, d.gnb_x2, d.gnb_c1, d.gnb_silu = ptr(x1), ptr(x2), c1, int(pre_silu)
+                d.gnb_a, d.gnb_b = ptr(pre["a"]), ptr(pre["b"])
+                d.gna_g, d.gna_cA, d.gna_cP, d.gna_cQ = ptr(dact), ptr(cA), ptr(cP), ptr(cQ)
+                self.keep.append(d)
+                self.fwd_descs.append(d)
+                emit(lambda s, d=d: L.rho_conv_nd_fwd(C.byref(d), s), "dgrad", flops=2.0 * N_ * S_ * Cc * scw.cout,
+                     nbytes=float(esz) * (sk_dY.numel() + 3.0 * N_ * S_ * Cc))
+                pool.put(sk_dY)
+            elif drop is not None:
                 a3d = a3 + (float(drop[0]), int(drop[1]), ptr(self.drop_ctr))
                 emit(lambda s, a=a3d: L.rho_gn_bwd_apply_drop(*a, s), "gn_bwd_apply", nbytes=nb3)
             else:
@@ -1394,8 +1430,13 @@ class _Plan:
             for t in (cA, cP, cQ, work):
                 pool.put(t)
 
-        def dgrad(node, dY: Tensor, dyw: int, after_launch: Optional[Callable[[], None]] = None):
+        def dgrad(node, dY: Tensor, dyw: int, after_launch: Optional[Callable[[], None]] = None, hold_skip: bool = True):
+            """Data gradient of a conv node.  Returns True when the launch was held back: the 1x1x1 skip convolution of a ResBlock
+            whose in-conv path ends in a GroupNorm backward of the same inputs - it runs inside that pass (gn_backward's ``skip``)."""
             cw = node["cw"]
+            if hold_skip and id(node) in skip_partner:
+                held_skips[skip_partner[id(node)]] = (node, dY, dyw)
+                return True
             x1, x2, pre = node["x1"], node["x2"], node["pre"]
             c1 = x1.shape[-1]
             c2 = x2.shape[-1] if x2 is not None else 0
@@ -1440,7 +1481,7 @@ class _Plan:
                 if after_launch is not None:
                     after_launch()                    # (the deferred weight gradient starts here, on the side stream)
                 if pre is not None:
-                    gn_backward(pre, node["pre_silu"], x1, x2, dact, fused, drop=node.get("drop"))
+                    gn_backward(pre, node["pre_silu"], x1, x2, dact, fused, drop=node.get("drop"), skip=held_skips.pop(id(node), None))
                     if fused is not None:
                         pool.put(fused[0])
                 else:   # upsample: sum the 2x2 (1x2) children
@@ -1540,6 +1581,18 @@ class _Plan:
             written.add(key(head["y2"]))
 
         rs_hw = (1, 1) if eng.dims >= 2 else (0, 1)
+        # 1x1x1 skip-conv nodes whose block input also feeds a normalised conv (the block's in-conv, an earlier node): id(skip node) ->
+        # id(in-conv node).  Their data gradient is held until that node's GroupNorm backward (fuse_skip_dgrad)
+        if self.fuse_skip_dgrad:
+            for i, nd in enumerate(self.nodes):
+                if (nd["k"] == "conv" and nd["cw"].taps == 1 and nd["pre"] is None and not nd["stem"] and nd["up_hw"] == (0, 0)
+                        and tuple(nd["stride_hw"]) == (1, 1) and nd["res"] is None and not nd.get("phased") and not nd.get("s2")):
+                    for pj in range(i - 1, -1, -1):
+                        pn = self.nodes[pj]
+                        if (pn["k"] == "conv" and pn["pre"] is not None and pn["x1"] is nd["x1"] and pn["x2"] is nd["x2"]
+                                and pn["up_hw"] == (0, 0) and not pn["stem"]):
+                            skip_partner[id(nd)] = id(pn)
+                            break
         for node in reversed(self.nodes):
             if node["k"] == "head_direct":
                 continue                                       # (handled above)
@@ -1627,8 +1680,9 @@ class _Plan:
             defer["on"] = ov
             bias_and_wgrad(node, dY, dyw)
             defer["on"] = False
+            held_skip = False
             if not node["stem"]:
-                dgrad(node, dY, dyw, after_launch=flush_side if ov else None)
+                held_skip = bool(dgrad(node, dY, dyw, after_launch=flush_side if ov else None))
             if ov:
                 if defer["ops"]:
                     raise hip.RhoHipError("internal: deferred weight-gradient launches were never issued (backward plan)")
@@ -1636,7 +1690,7 @@ class _Plan:
             # the output gradient is dead now unless a residual aliased it
             aliased = node["res"] is not None and G.get(key(node["res"])) is dY
             G.pop(key(out_t), None)
-            if not aliased and not held_for_add:
+            if not aliased and not held_for_add and not held_skip:
                 pool.put(dY)
             ps = [] if use_arena else [cw.weight, cw.bias_param]      # (arena: reported with their finalize batch)
             if node["pre"] is not None:
@@ -1648,6 +1702,8 @@ class _Plan:
 
         if pending_add:
             raise hip.RhoHipError("internal: a residual gradient was never added (backward plan)")
+        if held_skips:
+            raise hip.RhoHipError("internal: a held skip data gradient was never launched (backward plan)")
         if use_arena:
             fin_close(force=True)
             arena["t"] = torch.empty(max(arena["floats"], 64), dtype=torch.float32, device=dev)

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("RHO_HIP_LIB") or os.path.join(_HERE, "librho_hip.so")
 
 RHO_F32 = 0
 RHO_BF16 = 1
-ABI_VERSION = 7      # == RHO_ABI_VERSION of include/rho_hip.h (tests/test_cabi.py keeps the two equal)
+ABI_VERSION = 8      # == RHO_ABI_VERSION of include/rho_hip.h (tests/test_cabi.py keeps the two equal)
 
 c_void_p, c_int, c_int32, c_int64, c_uint64, c_float, c_double = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
 
@@ -38,6 +38,7 @@ class ConvDesc(C.Structure):
         ("gnb_x1", c_void_p), ("gnb_x2", c_void_p), ("gnb_c1", c_int32), ("gnb_silu", c_int32), ("gnb_a", c_void_p), ("gnb_b", c_void_p),
         ("ws", c_void_p), ("ws_bytes", c_int64),
         ("sk_x1", c_void_p), ("sk_x2", c_void_p), ("sk_w", c_void_p), ("sk_bias", c_void_p), ("sk_c1", c_int32), ("sk_c2", c_int32),
+        ("gna_g", c_void_p), ("gna_cA", c_void_p), ("gna_cP", c_void_p), ("gna_cQ", c_void_p),
     ]
 
 

@@ -83,7 +83,7 @@ def test_conv_desc_struct_layout():
         fields.append(first)
         fields.extend(n.strip().lstrip("*") for n in names[1:])
     assert [f[0] for f in ConvDesc._fields_] == fields
-    assert ctypes.sizeof(ConvDesc) == 10 * 8 + 26 * 4 + 8 + 8 + 4 * 4 + (2 * 8 + 2 * 4 + 2 * 8) + 2 * 8 + (4 * 8 + 2 * 4)
+    assert ctypes.sizeof(ConvDesc) == 10 * 8 + 26 * 4 + 8 + 8 + 4 * 4 + (2 * 8 + 2 * 4 + 2 * 8) + 2 * 8 + (4 * 8 + 2 * 4) + 4 * 8
 
 
 def _gfx950_code_objects(path):

@@ -414,6 +414,83 @@ def test_folded_skip_is_refused_where_no_variant_exists(ops):
     assert rc(BF16, (3, 3, 3), 64, (8, 8, 8), stride_hw=(2, 2)) != 0
 
 
+# ----------------------------------------------------------------------------- GroupNorm backward apply in a data-gradient epilogue
+GNA_CASES = [("gna_bf16_bm32", "bf16", 64, 64, 32, (2, 4, 8, 8)), ("gna_bf16_bm64", "bf16", 64, 128, 64, (2, 8, 8, 8)),
+             ("gna_bf16_bm128", "bf16", 128, 256, 128, (3, 4, 8, 8)), ("gna_f32_bm64", "fp32", 32, 64, 64, (2, 1, 16, 16)),
+             ("gna_f32_bm32", "fp32", 32, 64, 32, (2, 1, 16, 16)), ("gna_f32_bm128", "fp32", 64, 128, 128, (2, 1, 16, 16))]
+
+
+def _run_gn_apply(ops, case, check=True):
+    """rho_conv_desc.gna_*: the 1x1x1 skip convolution's data gradient with the GroupNorm backward apply of the same block input in
+    its epilogue (one launch, both concat sources) against the two passes it replaces - the plain two-output data gradient, then
+    rho_gn_bwd_apply accumulating into it - and against the formula in fp32."""
+    from rho_diffusion_amd import hip
+    from rho_diffusion_amd.hip import dtype_code, ptr
+    name, dtype, cy, c1, c2, shape = case
+    L = hip.lib()
+    td = BF16 if dtype == "bf16" else F32
+    dtc = dtype_code(td)
+    N, D, H, W = shape
+    S, Cc = D * H * W, c1 + c2
+    dy = det_normal((N, D, H, W, cy), name + "dy").to(DEV).to(td)
+    x1 = det_normal((N, D, H, W, c1), name + "x1").to(DEV).to(td)
+    x2 = det_normal((N, D, H, W, c2), name + "x2").to(DEV).to(td)
+    g = det_normal((N, D, H, W, Cc), name + "g").to(DEV).to(td)
+    a = (1.0 + 0.3 * det_normal((N, Cc), name + "a")).to(DEV)
+    b = (0.2 * det_normal((N, Cc), name + "b")).to(DEV)
+    cA = (0.5 * det_normal((N, Cc), name + "cA")).to(DEV)
+    cP = (0.1 * det_normal((N, 32), name + "cP")).to(DEV)
+    cQ = (0.1 * det_normal((N, 32), name + "cQ")).to(DEV)
+    wsk = (det_normal((cy, Cc, 1, 1, 1), name + "w") * 0.1).to(DEV)          # the skip conv's weight [cout = cy][cin = Cc]
+    wd = ops.prep_conv_weight_dgrad(wsk, td)                                  # data-gradient layout: Cc rows out of cy columns
+    zb = torch.zeros(wd.shape[1], device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def outs():
+        return (torch.full((N, D, H, W, c1), float("nan"), dtype=td, device=DEV), torch.full((N, D, H, W, c2), float("nan"), dtype=td, device=DEV))
+
+    f1, f2 = outs()
+    d1 = ops.make_conv_desc(dy, None, wd, zb, kernel=(1, 1, 1), cout=Cc, split=c1, y=f1, y2=f2, y2_cl=True)
+    d1.gnb_x1, d1.gnb_x2, d1.gnb_c1, d1.gnb_silu = ptr(x1), ptr(x2), c1, 1
+    d1.gnb_a, d1.gnb_b = ptr(a), ptr(b)
+    d1.gna_g, d1.gna_cA, d1.gna_cP, d1.gna_cQ = ptr(g), ptr(cA), ptr(cP), ptr(cQ)
+    variants = {ops.conv_variant(d1)}
+    assert all(v.endswith("+gn_apply") for v in variants), variants
+    if not check:
+        return variants
+    # reference: two passes
+    r1, r2 = outs()
+    d0 = ops.make_conv_desc(dy, None, wd, zb, kernel=(1, 1, 1), cout=Cc, split=c1, y=r1, y2=r2, y2_cl=True)
+    ops.conv_launch(d0)
+    assert L.rho_gn_bwd_apply(ptr(g), ptr(x1), c1, ptr(x2), c2, dtc, N, S, ptr(a), ptr(b), 1, ptr(cA), ptr(cP), ptr(cQ), ptr(r1), ptr(r2),
+                              1, 1, None, st) == 0
+    ops.conv_launch(d1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(f1.float()).all() and torch.isfinite(f2.float()).all()
+    tol = 2e-6 if dtype == "fp32" else 6e-3        # (bf16: the two-pass form rounds the data gradient before the apply term joins it)
+    assert rel_l2(f1.float(), r1.float()) < tol and rel_l2(f2.float(), r2.float()) < tol
+    xcat = torch.cat([x1, x2], -1).float()
+    z = a[:, None, None, None, :] * xcat + b[:, None, None, None, :]
+    sg = torch.sigmoid(z)
+    dz = g.float() * sg * (1.0 + z * (1.0 - sg))
+    grp = torch.arange(Cc, device=DEV) // (Cc // 32)
+    ref = (torch.einsum("ndhwk,kc->ndhwc", dy.float(), wsk.reshape(cy, Cc)) + cA[:, None, None, None, :] * dz
+           + cQ[:, grp][:, None, None, None, :] * xcat + cP[:, grp][:, None, None, None, :])
+    got = torch.cat([f1, f2], -1).float()
+    assert rel_l2(got, ref) < (2e-6 if dtype == "fp32" else 5e-3)
+    # refused where it cannot run: with a residual operand
+    d1.res = ptr(f1)
+    with pytest.raises(hip.RhoHipError):
+        ops.conv_launch(d1)
+    return variants
+
+
+@pytest.mark.parametrize("case", GNA_CASES, ids=[c[0] for c in GNA_CASES])
+def test_gn_backward_apply_in_the_data_gradient_epilogue(ops, case):
+    _run_gn_apply(ops, case)
+
+
+
 def test_parity_cases_cover_every_variant_the_bench_plans_launch(ops):
     """c3 (3-D 64^3 mc 64 bf16), c5 (3-D 128^3 mc 32 conditioned bf16), c2 (2-D 128^2 mc 64 fp32): inference and training plans.
     (The plan's variants depend on the per-sample geometry, not on the batch: batch 1 / 4 as in the parity cases.)"""
@@ -423,6 +500,8 @@ def test_parity_cases_cover_every_variant_the_bench_plans_launch(ops):
         covered |= _SEEN.get(case[0]) or _run_layer(ops, case, check=False)
     for case in FOLD_CASES:
         covered |= _run_fold_skip(ops, case, check=False)
+    for case in GNA_CASES:
+        covered |= _run_gn_apply(ops, case, check=False)
     plans = {
         "c3": (dict(base, model_channels=64, dims=3, data_shape=[64, 64, 64]), (1, 1, 64, 64, 64), BF16, False),
         "c5": (dict(base, model_channels=32, dims=3, data_shape=[128, 128, 128], num_classes=25), (1, 1, 128, 128, 128), BF16, True),

@@ -2,6 +2,7 @@
 slabs instead of fp32 atomics, ordered linear / label-embedding backward, ordered MSE reduction), the plan key (use_checkpoint flags
 and A/B switches select another plan instead of silently replaying the old one), and the small ABI-7 additions."""
 import ctypes as C
+import math
 
 import pytest
 import torch
@@ -316,3 +317,43 @@ def test_dropout_matches_the_oracle_under_the_same_masks_and_is_off_in_eval(case
         model(x.to(DEV), t.to(DEV))                            # the next forward draws a fresh stretch of every stream
         again = next(iter(_dropout_masks(model, model.engine()._last_train_plan).values()))[0]
         assert not torch.equal(first, again)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,dims,grid", [("bf16", 3, 32), ("fp32", 2, 32)])
+def test_skip_data_gradient_with_the_groupnorm_apply_in_its_epilogue_equals_the_two_pass_plan(monkeypatch, dtype, dims, grid):
+    """Training plans with RHO_FUSE_SKIP_DGRAD on / off (the ResBlocks with a 1x1x1 skip convolution: their input gradient in one
+    launch instead of a data-gradient launch + an apply pass): the fused plan has fewer apply passes, every parameter gradient and the
+    input-side activations' gradients (through the parameters upstream) agree."""
+    from test_gpu_round3 import _bench_unet
+    x = det_normal((2, 1) + (grid,) * dims, "r4fsx").to(DEV)
+    t = torch.tensor([321, 45], device=DEV)
+    grads, napply, ndg = [], [], []
+    for on in ("1", "0"):
+        monkeypatch.setenv("RHO_FUSE_SKIP_DGRAD", on)
+        model = _bench_unet(dims, grid, 32, dtype, False)
+        model.train()
+        pred = model(x, t)
+        (pred.float() ** 2).mean().backward()
+        grads.append({n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None})
+        plan = [p for p in model.engine()._plans.values() if p.train][0]
+        kinds = [i["kind"] for i in plan.bwd_info]
+        napply.append(kinds.count("gn_bwd_apply"))
+        ndg.append(kinds.count("dgrad"))
+        del model, plan
+        torch.cuda.empty_cache()
+    assert napply[0] < napply[1] and ndg[0] == ndg[1]          # one apply pass per skip-conv block is gone, no launch was added
+    assert set(grads[0]) == set(grads[1])
+    gtot = math.sqrt(sum(float(g.double().norm()) ** 2 for g in grads[1].values()))
+    tol_c, tol_n = (0.995, 0.05) if dtype == "bf16" else (0.999999, 1e-4)
+    bad = []
+    for n in grads[0]:
+        a, b = grads[0][n].flatten().double(), grads[1][n].flatten().double()
+        if float(b.norm()) < 1e-4 * gtot:
+            if float(a.norm()) > 1e-3 * gtot:
+                bad.append((n, "should be ~0", float(a.norm()), float(b.norm())))
+            continue
+        c = float(torch.dot(a, b) / (a.norm() * b.norm()))
+        if c < tol_c or abs(float(a.norm()) - float(b.norm())) > tol_n * float(b.norm()):
+            bad.append((n, round(c, 6), float(a.norm()), float(b.norm())))
+    assert not bad, bad[:8]
