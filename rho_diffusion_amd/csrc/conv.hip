@@ -1320,6 +1320,8 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
     }
 }
 
+#include "conv32.h"
+
 // ------------------------------------------------------------------------------------------ host
 namespace {
 
@@ -1450,6 +1452,15 @@ static int conv_impl(const rho_conv_desc* dp, void* stream, int64_t* stats_tiles
         return RHO_E_ARG;
     if ((d.ph_h || d.phd_h || d.ph_w || d.phd_w) && d.kd * d.kh * d.kw == 1) return RHO_E_ARG;   // (the 1x1x1 path merges the axes)
     if ((d.phd_h || d.phd_w) && (d.kd == 2 || d.pre_a)) return RHO_E_ARG;
+
+    // the 32 -> 32 channel 3x3x3 layers: the persistent register-resident-weights kernel (conv32.h)
+    if (conv32_applies(d)) {
+        if (stats_tiles) { *stats_tiles = conv32_wps(d); return 0; }
+        if (ws_want) { *ws_want = 0; return 0; }
+        if (g_variant != nullptr) { snprintf(g_variant->buf, (size_t)g_variant->cap, "k_conv32<bf16>"); return 0; }
+        if (d.stats && d.split != d.cout) return RHO_E_ARG;
+        return launch_conv32(d, as_stream(stream));
+    }
 
     // output extents per sample (padding k/2).  Zero-stuffed input (dgrad of a stride-2 conv): the
     // virtual input and the output both have the forward conv's input extent out_h / out_w.
