@@ -414,6 +414,59 @@ def test_folded_skip_is_refused_where_no_variant_exists(ops):
     assert rc(BF16, (3, 3, 3), 64, (8, 8, 8), stride_hw=(2, 2)) != 0
 
 
+# ----------------------------------------------------------------------------- k_conv32 (persistent 32 -> 32 channel kernel): edge geometries
+@pytest.mark.parametrize("N,spatial,prologue,residual,emb", [
+    (1, (4, 8, 8), True, True, False),        # one tile: every face of the volume in the same halo
+    (3, (8, 16, 24), True, False, True),      # 12 tiles per sample, 85 workgroups per sample asked for: clamped to the tile count
+    (2, (12, 8, 16), False, True, True),      # no prologue (training plans: materialised inputs)
+    (5, (16, 16, 16), True, True, True),      # odd batch: uneven tile ranges per workgroup
+], ids=["one_tile", "n3_ragged", "plain", "n5"])
+def test_conv32_edge_geometries_against_the_oracle(ops, N, spatial, prologue, residual, emb):
+    """3x3x3, 32 -> 32 channels, bf16 on small volumes: first / last tiles of every axis, several tiles per workgroup, the additive
+    embedding row, the residual, and the per-workgroup GroupNorm statistics - against the CPU oracle's conv of the rounded operands."""
+    dtype, c = BF16, 32
+    name = "c32e%d%s" % (N, "x".join(map(str, spatial)))
+    x = rnd(det_normal((N, c, *spatial), name + "x"), dtype)
+    w = rnd(det_normal((c, c, 3, 3, 3), name + "w") / math.sqrt(c * 27), dtype)
+    b = det_normal((c,), name + "b") * 0.1
+    pre = (1 + 0.3 * det_normal((N, c), name + "a"), 0.2 * det_normal((N, c), name + "pb")) if prologue else None
+    xa = x
+    if pre is not None:
+        shp = (N, c, 1, 1, 1)
+        xa = rnd(F.silu(pre[0].reshape(shp) * x + pre[1].reshape(shp)), dtype)
+    want = R.conv_nd(3, xa, w, b, stride=1, padding=1)
+    res = rnd(det_normal(tuple(want.shape), name + "r"), dtype) if residual else None
+    e = det_normal((N, c), name + "e") * 0.2 if emb else None
+    if residual:
+        want = want + res
+    if emb:
+        want = want + e.reshape(N, c, 1, 1, 1)
+    wp = ops.prep_conv_weight(w.to(DEV), dtype)
+    bp = b.to(DEV).clone()
+    y = torch.full((N, *spatial, c), float("nan"), dtype=dtype, device=DEV)
+    keep = [pre[0].to(DEV), pre[1].to(DEV)] if pre else [None, None]
+    ed = e.to(DEV).contiguous() if emb else None
+    d = ops.make_conv_desc(to_cl(x, dtype), None, wp, bp, kernel=(3, 3, 3), cout=c, split=c, y=y, y2=None, pre_a=keep[0], pre_b=keep[1],
+                           pre_silu=True, res=to_cl(res, dtype) if residual else None, res_add=ed, res_add_stride=c if emb else 0)
+    assert ops.conv_variant(d) == "k_conv32<bf16>"
+    tiles = ops.conv_stats_tiles(d)
+    assert 1 <= tiles <= (spatial[0] // 4) * (spatial[1] // 8) * (spatial[2] // 8)
+    sbuf = torch.full((N * tiles * 2 * c,), float("nan"), device=DEV)
+    d.stats = sbuf.data_ptr()
+    ops.conv_launch(d)
+    torch.cuda.synchronize()
+    got = from_cl(y, 3)
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, want) < 6e-3, rel_l2(got, want)
+    st = sbuf.view(N, tiles, 2, c).sum(1)
+    yy = y.float().reshape(N, -1, c)
+    assert rel_l2(st[:, 0], yy.sum(1)) < 1e-3 and rel_l2(st[:, 1], (yy * yy).sum(1)) < 1e-3
+    # a volume that is not whole tiles stays on the generic kernel
+    xo = torch.zeros(1, 6, 8, 8, c, dtype=dtype, device=DEV)
+    do = ops.make_conv_desc(xo, None, wp, bp, kernel=(3, 3, 3), cout=c, split=c, y=torch.empty_like(xo), y2=None)
+    assert ops.conv_variant(do).startswith("k_conv<")
+
+
 # ----------------------------------------------------------------------------- GroupNorm backward apply in a data-gradient epilogue
 GNA_CASES = [("gna_bf16_bm32", "bf16", 64, 64, 32, (2, 4, 8, 8)), ("gna_bf16_bm64", "bf16", 64, 128, 64, (2, 8, 8, 8)),
              ("gna_bf16_bm128", "bf16", 128, 256, 128, (3, 4, 8, 8)), ("gna_f32_bm64", "fp32", 32, 64, 64, (2, 1, 16, 16)),
