@@ -31,6 +31,10 @@ BWD_CASES = [
     ("3d_basic", 3, 2, 32, 0, 64, (4, 8, 8), 3, 1, False),
     ("3d_ragged", 3, 1, 64, 0, 32, (5, 6, 7), 3, 1, False),
     ("3d_concat", 3, 2, 64, 32, 64, (4, 8, 8), 3, 1, False),
+    # (round 4, k_wgrad's per-tile validity masks: several tiles per axis with overhanging last tiles; whole tiles = the GEO variant)
+    ("3d_multi_ragged", 3, 2, 32, 0, 64, (9, 20, 12), 3, 1, False),
+    ("3d_multi_whole", 3, 1, 64, 0, 64, (12, 24, 16), 3, 1, False),
+    ("2d_multi_ragged", 2, 2, 64, 0, 64, (40, 36), 3, 1, False),
     ("3d_down", 3, 2, 32, 0, 32, (4, 8, 8), 3, (1, 2, 2), False),
     ("3d_down_odd", 3, 1, 32, 0, 64, (3, 7, 9), 3, (1, 2, 2), False),
     ("3d_up", 3, 2, 32, 0, 32, (4, 4, 4), 3, 1, True),
