@@ -13,9 +13,10 @@ extern "C" int rho_gn_nblk(int64_t s) {
     // position blocks per sample of the partial-sum passes.  256 positions per block: with wide channel counts a block
     // covers only 256 / (C/8) positions per iteration, and at the deep levels (S = 4096, C = 512..1024) 2048-position
     // blocks meant 64 workgroups on 256 CUs running 1024 serial iterations each (0.65 TB/s).
+    // (round 4: up to 256 blocks, was 64 - a batch of 2 at 128^3 gave the backward reduction 128 workgroups on 256 CUs: 1.3 TB/s)
     int64_t nb = (s + 255) / 256;
     if (nb < 1) nb = 1;
-    if (nb > 64) nb = 64;
+    if (nb > 256) nb = 256;
     return (int)nb;
 }
 
@@ -601,7 +602,7 @@ static int apply_nblk(int64_t s, int64_t per, int64_t C, int64_t n) {
         nblk = want < cap ? want : cap;
     }
     if (nblk < 1) nblk = 1;
-    if (nblk > 256) nblk = 256;
+    if (nblk > 1024) nblk = 1024;        // (round 4: was 256 - 512 workgroups for a batch of 2 at 128^3 left the passes at 3.6 - 4.3 TB/s)
     return (int)nblk;
 }
 
